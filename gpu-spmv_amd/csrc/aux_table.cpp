@@ -1,0 +1,84 @@
+// aux_table.cpp — side tables for per-matrix auxiliary device data.
+//
+// CSRMatrix / ELLMatrix keep the reference's layout, so what the kernels
+// precompute (row statistics, merge-path tile table, ELL slot count) is keyed
+// by the matrix's device index array and dropped in csr_free_gpu / ell_free_gpu.
+#include "internal.h"
+
+#include <mutex>
+#include <unordered_map>
+
+namespace spmv {
+namespace detail {
+
+namespace {
+
+std::mutex g_lock;
+std::unordered_map<const void*, CsrAux*>& csr_table() {
+    static auto* t = new std::unordered_map<const void*, CsrAux*>();
+    return *t;
+}
+std::unordered_map<const void*, EllAux*>& ell_table() {
+    static auto* t = new std::unordered_map<const void*, EllAux*>();
+    return *t;
+}
+
+void release(CsrAux* a) {
+    if (a->d_tile_rows) (void)hipFree(a->d_tile_rows);
+    if (a->d_carry_row) (void)hipFree(a->d_carry_row);
+    if (a->d_carry_val) (void)hipFree(a->d_carry_val);
+    delete a;
+}
+
+} // namespace
+
+CsrAux* aux_lookup(const void* key, bool create) {
+    if (!key) return nullptr;
+    std::lock_guard<std::mutex> guard(g_lock);
+    auto& t = csr_table();
+    auto it = t.find(key);
+    if (it != t.end()) return it->second;
+    if (!create) return nullptr;
+    CsrAux* a = new CsrAux();
+    t.emplace(key, a);
+    return a;
+}
+
+void aux_drop(const void* key) {
+    if (!key) return;
+    CsrAux* victim = nullptr;
+    {
+        std::lock_guard<std::mutex> guard(g_lock);
+        auto& t = csr_table();
+        auto it = t.find(key);
+        if (it == t.end()) return;
+        victim = it->second;
+        t.erase(it);
+    }
+    release(victim);
+}
+
+EllAux* ell_aux_lookup(const void* key, bool create) {
+    if (!key) return nullptr;
+    std::lock_guard<std::mutex> guard(g_lock);
+    auto& t = ell_table();
+    auto it = t.find(key);
+    if (it != t.end()) return it->second;
+    if (!create) return nullptr;
+    EllAux* a = new EllAux();
+    t.emplace(key, a);
+    return a;
+}
+
+void ell_aux_drop(const void* key) {
+    if (!key) return;
+    std::lock_guard<std::mutex> guard(g_lock);
+    auto& t = ell_table();
+    auto it = t.find(key);
+    if (it == t.end()) return;
+    delete it->second;
+    t.erase(it);
+}
+
+} // namespace detail
+} // namespace spmv

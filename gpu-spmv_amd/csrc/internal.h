@@ -1,0 +1,72 @@
+// internal.h — helpers shared by the library's translation units (not installed).
+#ifndef SPMV_AMD_INTERNAL_H
+#define SPMV_AMD_INTERNAL_H
+
+#include "spmv/common.h"
+#include "spmv/csr_matrix.h"
+#include "spmv/ell_matrix.h"
+#include "spmv/spmv.h"
+
+#include <cstddef>
+#include <cstdint>
+
+namespace spmv {
+namespace detail {
+
+inline int code(SpMVError e) { return static_cast<int>(e); }
+
+// ---- per-matrix auxiliary data (side table keyed by the device row_ptrs) ----
+// The public structs cannot grow (callers poke the fields), so anything the
+// kernels precompute for a matrix lives here and is dropped by csr_free_gpu.
+struct CsrAux {
+    // row-length statistics computed once (host scan or device reduction)
+    bool   have_stats = false;
+    CSRStats stats{};
+    // merge-path partition: first row of every tile, built on first use
+    int*   d_tile_rows = nullptr;    // [num_tiles + 1]
+    int    num_tiles = 0;
+    int    tile_items = 0;
+    // merge-path carry-out slots
+    int*   d_carry_row = nullptr;    // [num_tiles]
+    float* d_carry_val = nullptr;    // [num_tiles]
+};
+
+CsrAux* aux_lookup(const void* key, bool create);
+void    aux_drop(const void* key);
+
+struct EllAux {
+    bool have_nnz = false;
+    long long actual_nnz = 0;   // non-padding slots, counted once on the device
+};
+EllAux* ell_aux_lookup(const void* key, bool create);
+void    ell_aux_drop(const void* key);
+
+// ---- launch layer (kernels.hip) ----
+// All return hipError_t from the launch; none synchronise.
+hipError_t launch_csr_scalar(const CSRMatrix* A, const float* d_x, float* d_y, hipStream_t s);
+hipError_t launch_csr_vector(const CSRMatrix* A, const float* d_x, float* d_y,
+                             int lanes_per_row, hipStream_t s);
+hipError_t launch_csr_merge(const CSRMatrix* A, CsrAux* aux, const float* d_x, float* d_y,
+                            hipStream_t s);
+hipError_t launch_ell(const ELLMatrix* A, const float* d_x, float* d_y, hipStream_t s);
+hipError_t launch_fill_zero(float* d_y, size_t n, hipStream_t s);
+hipError_t device_count_ell_nnz(const ELLMatrix* A, long long* out, hipStream_t s);
+hipError_t device_row_stats(const int* d_row_ptrs, int num_rows, int* max_out, int* min_out,
+                            hipStream_t s);
+
+// lanes-per-row choice for VECTOR_CSR from the mean row length (wave64 tuning)
+int pick_lanes_per_row(float avg_nnz_per_row);
+
+// timing helper: a cached event pair per thread
+struct EventPair {
+    hipEvent_t start = nullptr;
+    hipEvent_t stop = nullptr;
+};
+EventPair& thread_events();
+
+hipStream_t current_stream();
+
+} // namespace detail
+} // namespace spmv
+
+#endif

@@ -1,0 +1,440 @@
+// pagerank.hip — device-resident PageRank power iteration.
+//
+// Same mathematics and stop rule as the reference's host loop
+// (src/pagerank.cu:50-153):
+//     s      = sum of r_old over dangling nodes (columns whose stored values sum to 0)
+//     r_new  = d * (A r_old) + d * s / n + (1 - d) / n
+//     stop when ||r_new - r_old||_2 < tol or after max_iterations
+//     result = last computed vector, divided by its sum
+// but nothing crosses PCIe inside the loop: one fused kernel per iteration does
+// the vector-CSR SpMV, the damping/teleport update, and the partial sums for the
+// residual and the next dangling mass; a one-workgroup kernel folds the partials
+// in a fixed order (double accumulators) and raises a `done` flag on the device.
+// Kernels return immediately once `done` is set, so the host may run ahead of the
+// convergence check without changing the result.
+//
+// The same kernels serve the row-sharded multi-GPU loop (pr_* entry points):
+// each rank owns rows [row_offset, row_offset + local_rows) of A and a
+// full-length rank vector; the host all-reduces the two partial sums and
+// all-gathers the new slice (RCCL) between `pr_reduce` and `pr_commit`.
+#include "internal.h"
+#include "device_common.h"
+#include "pagerank_engine.h"
+#include "spmv/pagerank.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace spmv {
+namespace detail {
+
+namespace {
+
+using namespace dev;
+
+// block-wide sum of two doubles; result valid in thread 0
+__device__ __forceinline__ void block_sum2(double& a, double& b) {
+    __shared__ double s_a[kBlock / 64];
+    __shared__ double s_b[kBlock / 64];
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_a[wave] = a;
+        s_b[wave] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = s_a[0];
+        b = s_b[0];
+        for (int w = 1; w < kBlock / 64; ++w) {
+            a += s_a[w];
+            b += s_b[w];
+        }
+    }
+    __syncthreads();
+}
+
+// One power-iteration step over this shard's rows.
+template <int LANES>
+__global__ __launch_bounds__(kBlock)
+void pr_step_kernel(int local_rows, int row_offset, int n_global, long long nnz,
+                    const int* __restrict__ row_ptrs,
+                    const int* __restrict__ cols,
+                    const float* __restrict__ vals,
+                    const float* __restrict__ r_old,            // full length
+                    float* __restrict__ r_new,                  // full length; slice written
+                    const unsigned char* __restrict__ dangling, // full length mask
+                    float damping,
+                    const PrState* __restrict__ state,
+                    double* __restrict__ block_partials) {      // [2 * gridDim.x]
+    if (state->done) return;
+
+    constexpr int kRowsPerBlock = kBlock / LANES;
+    const int lane = threadIdx.x % LANES;
+    const int slot = threadIdx.x / LANES;
+
+    // same expression order as the host loop: d * y + (d * s / n) + (1 - d) / n
+    const float teleport = (1.0f - damping) / n_global;
+    const float dangling_term = __fdiv_rn(__fmul_rn(damping, state->dangling_sum),
+                                          static_cast<float>(n_global));
+
+    double res2 = 0.0, mass = 0.0;
+    for (long long first = static_cast<long long>(blockIdx.x) * kRowsPerBlock; first < local_rows;
+         first += static_cast<long long>(gridDim.x) * kRowsPerBlock) {
+        const long long row = first + slot;
+        float acc = 0.0f;
+        if (row < local_rows) {
+            acc = row_partial_dot<LANES>(row_ptrs[row], row_ptrs[row + 1], lane, nnz, cols, vals, r_old);
+        }
+        acc = group_sum<LANES>(acc);
+        if (lane == 0 && row < local_rows) {
+            const long long node = row_offset + row;
+            const float fresh = __fadd_rn(__fadd_rn(__fmul_rn(damping, acc), dangling_term), teleport);
+            r_new[node] = fresh;
+            const float diff = __fsub_rn(fresh, r_old[node]);
+            res2 += static_cast<double>(__fmul_rn(diff, diff));
+            if (dangling[node]) mass += static_cast<double>(fresh);
+        }
+    }
+    block_sum2(res2, mass);
+    if (threadIdx.x == 0) {
+        block_partials[2 * blockIdx.x] = res2;
+        block_partials[2 * blockIdx.x + 1] = mass;
+    }
+}
+
+// Folds the block partials left to right into sums[0] (residual^2) and sums[1]
+// (dangling mass of r_new).  One workgroup; fixed order => reproducible.
+__global__ __launch_bounds__(kBlock)
+void pr_reduce_kernel(const double* __restrict__ block_partials, int num_blocks,
+                      const PrState* __restrict__ state, double* __restrict__ sums) {
+    if (state->done) return;
+    double res2 = 0.0, mass = 0.0;
+    for (int b = threadIdx.x; b < num_blocks; b += kBlock) {
+        res2 += block_partials[2 * b];
+        mass += block_partials[2 * b + 1];
+    }
+    block_sum2(res2, mass);
+    if (threadIdx.x == 0) {
+        sums[0] = res2;
+        sums[1] = mass;
+    }
+}
+
+// Applies the (already globally reduced) sums: residual, iteration count,
+// convergence flag, dangling mass for the next step.
+__global__ void pr_commit_kernel(const double* __restrict__ sums, float tolerance,
+                                 PrState* __restrict__ state) {
+    if (state->done) return;
+    const float residual = static_cast<float>(sqrt(sums[0]));
+    state->iterations += 1;
+    state->final_residual = residual;
+    state->dangling_sum = static_cast<float>(sums[1]);
+    if (residual < tolerance) {
+        state->converged = 1;
+        state->done = 1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock)
+void pr_fill_kernel(float* __restrict__ r, size_t n, float value) {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        r[i] = value;
+    }
+}
+
+// Column sums of the stored values (atomic fp32 adds; only `== 0` is consumed).
+__global__ __launch_bounds__(kBlock)
+void pr_colsum_kernel(long long nnz, const int* __restrict__ cols, const float* __restrict__ vals,
+                      int n_cols, float* __restrict__ col_sums) {
+    for (long long j = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; j < nnz;
+         j += static_cast<long long>(gridDim.x) * kBlock) {
+        const int c = cols[j];
+        if (c >= 0 && c < n_cols) atomicAdd(&col_sums[c], vals[j]);
+    }
+}
+
+// mask[c] = (col_sums[c] == 0); also the dangling mass of a constant vector.
+__global__ __launch_bounds__(kBlock)
+void pr_mask_kernel(const float* __restrict__ col_sums, int n, unsigned char* __restrict__ mask,
+                    unsigned long long* __restrict__ count) {
+    unsigned long long local = 0;
+    for (long long c = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; c < n;
+         c += static_cast<long long>(gridDim.x) * kBlock) {
+        const bool d = col_sums[c] == 0.0f;
+        mask[c] = d;
+        local += d;
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+}
+
+int grid_for(long long rows, int rows_per_block) {
+    const long long blocks = (rows + rows_per_block - 1) / rows_per_block;
+    return static_cast<int>(std::max(1LL, std::min<long long>(blocks, kMaxResidentBlocks)));
+}
+
+template <int LANES>
+hipError_t launch_step(const PrShard& sh, const float* r_old, float* r_new, float damping,
+                       hipStream_t s) {
+    pr_step_kernel<LANES><<<sh.grid, kBlock, 0, s>>>(
+        sh.local_rows, sh.row_offset, sh.n_global, sh.nnz, sh.d_row_ptrs, sh.d_cols, sh.d_vals,
+        r_old, r_new, sh.d_dangling, damping, sh.d_state, sh.d_block_partials);
+    return hipGetLastError();
+}
+
+} // namespace
+
+int pr_max_blocks() { return kMaxResidentBlocks; }
+
+void pr_shard_prepare(PrShard* sh) {
+    const float avg = sh->local_rows > 0 ? static_cast<float>(sh->nnz) / sh->local_rows : 0.0f;
+    sh->lanes = pick_lanes_per_row(avg);
+    sh->grid = grid_for(sh->local_rows, kBlock / sh->lanes);
+}
+
+hipError_t pr_step(const PrShard& sh, const float* r_old, float* r_new, float damping,
+                   hipStream_t s) {
+    if (sh.local_rows <= 0) return hipSuccess;
+    switch (sh.lanes) {
+        case 1:  return launch_step<1>(sh, r_old, r_new, damping, s);
+        case 2:  return launch_step<2>(sh, r_old, r_new, damping, s);
+        case 4:  return launch_step<4>(sh, r_old, r_new, damping, s);
+        case 8:  return launch_step<8>(sh, r_old, r_new, damping, s);
+        case 16: return launch_step<16>(sh, r_old, r_new, damping, s);
+        case 32: return launch_step<32>(sh, r_old, r_new, damping, s);
+        default: return launch_step<64>(sh, r_old, r_new, damping, s);
+    }
+}
+
+hipError_t pr_reduce(const PrShard& sh, double* d_sums, hipStream_t s) {
+    pr_reduce_kernel<<<1, kBlock, 0, s>>>(sh.d_block_partials, sh.local_rows > 0 ? sh.grid : 0,
+                                          sh.d_state, d_sums);
+    return hipGetLastError();
+}
+
+hipError_t pr_commit(const PrShard& sh, const double* d_sums, float tolerance, hipStream_t s) {
+    pr_commit_kernel<<<1, 1, 0, s>>>(d_sums, tolerance, sh.d_state);
+    return hipGetLastError();
+}
+
+hipError_t pr_fill(float* d_r, size_t n, float value, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    pr_fill_kernel<<<grid_for(static_cast<long long>(n), kBlock * 4), kBlock, 0, s>>>(d_r, n, value);
+    return hipGetLastError();
+}
+
+hipError_t pr_column_sums(long long nnz, const int* d_cols, const float* d_vals, int n_cols,
+                          float* d_col_sums, hipStream_t s) {
+    if (nnz == 0) return hipSuccess;
+    pr_colsum_kernel<<<grid_for(nnz, kBlock * 4), kBlock, 0, s>>>(nnz, d_cols, d_vals, n_cols, d_col_sums);
+    return hipGetLastError();
+}
+
+hipError_t pr_mask_from_column_sums(const float* d_col_sums, int n, unsigned char* d_mask,
+                                    unsigned long long* d_count, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    pr_mask_kernel<<<grid_for(n, kBlock * 4), kBlock, 0, s>>>(d_col_sums, n, d_mask, d_count);
+    return hipGetLastError();
+}
+
+} // namespace detail
+
+// ---------------------------------------------------------------------------
+// public single-GPU entry point
+// ---------------------------------------------------------------------------
+namespace {
+
+// Dangling columns exactly as the reference's host scan (src/pagerank.cu:20-48):
+// sequential fp32 column sums in storage order, dangling <=> sum == 0.0f.
+std::vector<unsigned char> dangling_mask_host(const CSRMatrix* A) {
+    const int n = A->num_cols;
+    std::vector<float> sums(std::max(n, 0), 0.0f);
+    for (int r = 0; r < A->num_rows; ++r) {
+        for (int j = A->row_ptrs[r]; j < A->row_ptrs[r + 1]; ++j) {
+            const int c = A->col_indices[j];
+            if (c >= 0 && c < n) sums[c] += A->values[j];
+        }
+    }
+    std::vector<unsigned char> mask(sums.size());
+    for (size_t c = 0; c < sums.size(); ++c) mask[c] = sums[c] == 0.0f;
+    return mask;
+}
+
+template <typename T>
+struct DeviceArray {
+    T* ptr = nullptr;
+    ~DeviceArray() { if (ptr) (void)hipFree(ptr); }
+    hipError_t alloc(size_t count) {
+        return hipMalloc(reinterpret_cast<void**>(&ptr), std::max<size_t>(count, 1) * sizeof(T));
+    }
+};
+
+} // namespace
+
+PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
+    PageRankResult result;
+    if (!adj) return result;
+
+    const PageRankConfig fallback;
+    if (!config) config = &fallback;
+
+    const int n = adj->num_rows;
+    result.ranks = new float[std::max(n, 0)];
+    const float start = n > 0 ? 1.0f / n : 0.0f;
+    std::fill_n(result.ranks, std::max(n, 0), start);
+    if (n <= 0) return result;
+
+    // The matrix must be resident on the device (csr_to_gpu), like the reference's
+    // spmv_csr call requires; otherwise the loop ends at once with the start vector.
+    if (!adj->d_row_ptrs || (adj->nnz > 0 && (!adj->d_col_indices || !adj->d_values))) {
+        return result;
+    }
+
+    hipStream_t stream = detail::current_stream();
+    using detail::PrState;
+
+    DeviceArray<float> r_a, r_b, col_sums;
+    DeviceArray<unsigned char> mask;
+    DeviceArray<double> partials, sums;
+    DeviceArray<PrState> state;
+    DeviceArray<unsigned long long> dangling_count;
+    // vectors are indexed by column during the SpMV and by row during the update
+    const size_t len = static_cast<size_t>(std::max(n, adj->num_cols));
+    if (r_a.alloc(len) != hipSuccess || r_b.alloc(len) != hipSuccess ||
+        mask.alloc(len) != hipSuccess ||
+        partials.alloc(2 * static_cast<size_t>(detail::pr_max_blocks())) != hipSuccess ||
+        sums.alloc(2) != hipSuccess || state.alloc(1) != hipSuccess ||
+        dangling_count.alloc(1) != hipSuccess) {
+        return result;
+    }
+
+    bool ok = hipMemsetAsync(mask.ptr, 0, len, stream) == hipSuccess
+           && hipMemsetAsync(dangling_count.ptr, 0, sizeof(unsigned long long), stream) == hipSuccess
+           && detail::pr_fill(r_a.ptr, len, start, stream) == hipSuccess
+           && detail::pr_fill(r_b.ptr, len, start, stream) == hipSuccess;
+
+    // dangling mask: host scan when host arrays exist (reference semantics), else on device
+    unsigned long long num_dangling = 0;
+    if (ok && adj->values && adj->col_indices && adj->row_ptrs) {
+        const std::vector<unsigned char> host_mask = dangling_mask_host(adj);
+        const size_t m = std::min(host_mask.size(), static_cast<size_t>(n));
+        for (size_t c = 0; c < m; ++c) num_dangling += host_mask[c];
+        ok = hipMemcpyAsync(mask.ptr, host_mask.data(), m, hipMemcpyHostToDevice, stream) == hipSuccess
+          && hipStreamSynchronize(stream) == hipSuccess;
+    } else if (ok) {
+        ok = col_sums.alloc(len) == hipSuccess
+          && hipMemsetAsync(col_sums.ptr, 0, len * sizeof(float), stream) == hipSuccess
+          && detail::pr_column_sums(adj->nnz, adj->d_col_indices, adj->d_values, adj->num_cols,
+                                    col_sums.ptr, stream) == hipSuccess
+          && detail::pr_mask_from_column_sums(col_sums.ptr, std::min(n, adj->num_cols), mask.ptr,
+                                              dangling_count.ptr, stream) == hipSuccess
+          && hipMemcpyAsync(&num_dangling, dangling_count.ptr, sizeof(num_dangling),
+                            hipMemcpyDeviceToHost, stream) == hipSuccess
+          && hipStreamSynchronize(stream) == hipSuccess;
+    }
+    if (!ok) return result;
+
+    // dangling mass of the start vector: the same left-to-right fp32 sum as the host loop
+    PrState host_state{};
+    for (unsigned long long k = 0; k < num_dangling; ++k) host_state.dangling_sum += start;
+    ok = hipMemcpyAsync(state.ptr, &host_state, sizeof(PrState), hipMemcpyHostToDevice, stream) == hipSuccess;
+
+    detail::PrShard shard;
+    shard.local_rows = n;
+    shard.row_offset = 0;
+    shard.n_global = n;
+    shard.nnz = adj->nnz;
+    shard.d_row_ptrs = adj->d_row_ptrs;
+    shard.d_cols = adj->d_col_indices;
+    shard.d_vals = adj->d_values;
+    shard.d_dangling = mask.ptr;
+    shard.d_state = state.ptr;
+    shard.d_block_partials = partials.ptr;
+    detail::pr_shard_prepare(&shard);
+
+    // Pinned mirrors of the device state, two deep: the host enqueues step k+1
+    // before it looks at the outcome of step k.
+    PrState* pinned = nullptr;
+    hipEvent_t seen[2] = {nullptr, nullptr};
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&pinned), 2 * sizeof(PrState)) == hipSuccess
+            && hipEventCreateWithFlags(&seen[0], hipEventDisableTiming) == hipSuccess
+            && hipEventCreateWithFlags(&seen[1], hipEventDisableTiming) == hipSuccess;
+
+    float* bufs[2] = {r_a.ptr, r_b.ptr};
+    for (int iter = 0; ok && iter < config->max_iterations; ++iter) {
+        const float* r_old = bufs[iter & 1];
+        float* r_new = bufs[(iter + 1) & 1];
+        ok = detail::pr_step(shard, r_old, r_new, config->damping_factor, stream) == hipSuccess
+          && detail::pr_reduce(shard, sums.ptr, stream) == hipSuccess
+          && detail::pr_commit(shard, sums.ptr, config->tolerance, stream) == hipSuccess
+          && hipMemcpyAsync(&pinned[iter & 1], state.ptr, sizeof(PrState),
+                            hipMemcpyDeviceToHost, stream) == hipSuccess
+          && hipEventRecord(seen[iter & 1], stream) == hipSuccess;
+        if (ok && iter >= 1) {
+            ok = hipEventSynchronize(seen[(iter - 1) & 1]) == hipSuccess;
+            if (ok && pinned[(iter - 1) & 1].done) break;
+        }
+    }
+
+    if (ok) {
+        ok = hipMemcpyAsync(&host_state, state.ptr, sizeof(PrState), hipMemcpyDeviceToHost, stream) == hipSuccess
+          && hipStreamSynchronize(stream) == hipSuccess;
+    }
+    if (ok) {
+        result.iterations = host_state.iterations;
+        result.final_residual = host_state.final_residual;
+        result.converged = host_state.converged != 0;
+        // the last written vector: step k (0-based) writes bufs[(k + 1) & 1]
+        const float* last = bufs[host_state.iterations & 1];
+        ok = hipMemcpy(result.ranks, last, static_cast<size_t>(n) * sizeof(float),
+                       hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (pinned) (void)hipHostFree(pinned);
+    for (hipEvent_t e : seen) if (e) (void)hipEventDestroy(e);
+    if (!ok) {
+        std::fill_n(result.ranks, n, start);
+        return result;
+    }
+
+    // final renormalisation (sum accumulated in double; the reference's fp32
+    // running sum loses digits at n ~ 1e7)
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total += result.ranks[i];
+    const float total_f = static_cast<float>(total);
+    if (total_f > 0.0f) {
+        for (int i = 0; i < n; ++i) result.ranks[i] /= total_f;
+    }
+    return result;
+}
+
+void pagerank_free(PageRankResult* result) {
+    if (result && result->ranks) {
+        delete[] result->ranks;
+        result->ranks = nullptr;
+    }
+}
+
+void pagerank_top_k(const PageRankResult* result, int num_nodes, int k, TopKNode* top_k) {
+    if (!result || !result->ranks || !top_k || k <= 0 || num_nodes <= 0) return;
+
+    std::vector<int> order(num_nodes);
+    for (int i = 0; i < num_nodes; ++i) order[i] = i;
+    const int keep = std::min(k, num_nodes);
+    const float* ranks = result->ranks;
+    std::partial_sort(order.begin(), order.begin() + keep, order.end(),
+                      [ranks](int a, int b) { return ranks[a] > ranks[b]; });
+    for (int i = 0; i < keep; ++i) {
+        top_k[i].node_id = order[i];
+        top_k[i].rank = ranks[order[i]];
+    }
+}
+
+} // namespace spmv

@@ -1,0 +1,53 @@
+// pagerank_engine.h — the per-shard PageRank step engine shared by the
+// single-GPU pagerank() and the row-sharded multi-GPU host loop (C-ABI pr_*).
+#ifndef SPMV_AMD_PAGERANK_ENGINE_H
+#define SPMV_AMD_PAGERANK_ENGINE_H
+
+#include "internal.h"
+
+namespace spmv {
+namespace detail {
+
+// Lives in device memory; every engine kernel reads `done` first.
+struct PrState {
+    float dangling_sum;     // dangling mass of the current r_old
+    float final_residual;   // ||r_new - r_old||_2 of the last committed step
+    int   iterations;       // committed steps
+    int   converged;        // residual < tolerance was observed
+    int   done;             // steps after this are no-ops
+    int   reserved;
+};
+
+// One rank's slice of the problem: rows [row_offset, row_offset + local_rows)
+// of the n_global x n_global matrix, CSR with row_ptrs rebased to 0.
+struct PrShard {
+    int local_rows = 0;
+    int row_offset = 0;
+    int n_global = 0;
+    long long nnz = 0;
+    const int* d_row_ptrs = nullptr;
+    const int* d_cols = nullptr;
+    const float* d_vals = nullptr;
+    const unsigned char* d_dangling = nullptr;   // [>= n_global] 1 = dangling node
+    PrState* d_state = nullptr;
+    double* d_block_partials = nullptr;          // [2 * pr_max_blocks()]
+    int lanes = 4;                               // lanes per row, from the mean row length
+    int grid = 1;
+};
+
+int pr_max_blocks();
+void pr_shard_prepare(PrShard* shard);
+hipError_t pr_step(const PrShard& shard, const float* d_r_old, float* d_r_new, float damping,
+                   hipStream_t s);
+hipError_t pr_reduce(const PrShard& shard, double* d_sums /*[2]*/, hipStream_t s);
+hipError_t pr_commit(const PrShard& shard, const double* d_sums, float tolerance, hipStream_t s);
+hipError_t pr_fill(float* d_r, size_t n, float value, hipStream_t s);
+hipError_t pr_column_sums(long long nnz, const int* d_cols, const float* d_vals, int n_cols,
+                          float* d_col_sums, hipStream_t s);
+hipError_t pr_mask_from_column_sums(const float* d_col_sums, int n, unsigned char* d_mask,
+                                    unsigned long long* d_count, hipStream_t s);
+
+} // namespace detail
+} // namespace spmv
+
+#endif

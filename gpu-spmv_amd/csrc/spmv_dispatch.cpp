@@ -1,0 +1,224 @@
+// spmv_dispatch.cpp — host entry points spmv_csr / spmv_ell: validation,
+// kernel choice, device-event timing, metric fill-in.
+//
+// Follows the reference's dispatcher contract (src/spmv_kernels.cu:215-326 for
+// CSR, :328-420 for ELL): argument checks in the same order with the same
+// error codes, nullptr config => {SCALAR_CSR, 256, false}, ELL_KERNEL passed to
+// spmv_csr behaves as SCALAR_CSR, elapsed_ms is kernel-only event time, the
+// call returns after the kernel completed, result.y aliases d_y.
+// Documented deviations:
+//   * a matrix with zero rows is a successful no-op (the reference's own
+//     EmptyMatrix test expects this; its code returns INVALID_DIMENSION);
+//   * nnz == 0 with rows > 0 succeeds and writes y = 0;
+//   * the ELL non-padding count behind `gflops` is taken once on the device
+//     and cached per matrix instead of an O(rows*K) host scan per call.
+#include "internal.h"
+#include "spmv/bandwidth.h"
+
+namespace spmv {
+
+namespace detail {
+
+namespace {
+thread_local hipStream_t g_stream = nullptr;
+}
+
+hipStream_t current_stream() { return g_stream; }
+
+EventPair& thread_events() {
+    thread_local EventPair pair;
+    if (!pair.start) {
+        if (hipEventCreate(&pair.start) != hipSuccess) pair.start = nullptr;
+        if (hipEventCreate(&pair.stop) != hipSuccess) pair.stop = nullptr;
+    }
+    return pair;
+}
+
+namespace {
+
+bool block_size_ok(const SpMVConfig* config) {
+    return config->block_size > 0 && config->block_size <= 1024;
+}
+
+// shared front half of the sync and async CSR paths; returns SUCCESS when a launch should follow
+int check_csr(const CSRMatrix* A, const float* d_x, float* d_y, int vec_size, bool* nothing_to_do) {
+    *nothing_to_do = false;
+    if (!A || !d_x || !d_y) return code(SpMVError::INVALID_ARGUMENT);
+    if (A->num_rows == 0) {
+        *nothing_to_do = true;
+        return code(SpMVError::SUCCESS);
+    }
+    if (vec_size >= 0 && !spmv_validate_dimensions(A->num_cols, vec_size)) {
+        return code(SpMVError::INVALID_DIMENSION);
+    }
+    if (!A->d_row_ptrs || (A->nnz > 0 && (!A->d_col_indices || !A->d_values))) {
+        return code(SpMVError::INVALID_FORMAT);
+    }
+    return code(SpMVError::SUCCESS);
+}
+
+hipError_t enqueue_csr(const CSRMatrix* A, const float* d_x, float* d_y,
+                       const SpMVConfig* config, hipStream_t stream) {
+    if (A->nnz == 0) return launch_fill_zero(d_y, A->num_rows, stream);
+
+    switch (config->kernel_type) {
+        case SpMVConfig::VECTOR_CSR: {
+            const float avg = static_cast<float>(A->nnz) / A->num_rows;
+            return launch_csr_vector(A, d_x, d_y, pick_lanes_per_row(avg), stream);
+        }
+        case SpMVConfig::MERGE_PATH: {
+            CsrAux* aux = aux_lookup(A->d_row_ptrs, true);
+            return launch_csr_merge(A, aux, d_x, d_y, stream);
+        }
+        case SpMVConfig::SCALAR_CSR:
+        default:
+            return launch_csr_scalar(A, d_x, d_y, stream);
+    }
+}
+
+int check_ell(const ELLMatrix* A, const float* d_x, float* d_y, int vec_size, bool* nothing_to_do) {
+    *nothing_to_do = false;
+    if (!A || !d_x || !d_y) return code(SpMVError::INVALID_ARGUMENT);
+    if (A->num_rows == 0) {
+        *nothing_to_do = true;
+        return code(SpMVError::SUCCESS);
+    }
+    if (vec_size >= 0 && !spmv_validate_dimensions(A->num_cols, vec_size)) {
+        return code(SpMVError::INVALID_DIMENSION);
+    }
+    if (A->max_nnz_per_row > 0 && (!A->d_col_indices || !A->d_values)) {
+        return code(SpMVError::INVALID_FORMAT);
+    }
+    return code(SpMVError::SUCCESS);
+}
+
+hipError_t enqueue_ell(const ELLMatrix* A, const float* d_x, float* d_y, hipStream_t stream) {
+    if (A->max_nnz_per_row == 0) return launch_fill_zero(d_y, A->num_rows, stream);
+    return launch_ell(A, d_x, d_y, stream);
+}
+
+// runs `enqueue` between a cached event pair on `stream` and waits for it
+template <typename Enqueue>
+int timed(hipStream_t stream, float* elapsed_ms, Enqueue&& enqueue) {
+    EventPair& ev = thread_events();
+    if (!ev.start || !ev.stop) return code(SpMVError::KERNEL_LAUNCH);
+    if (hipEventRecord(ev.start, stream) != hipSuccess) return code(SpMVError::KERNEL_LAUNCH);
+    const hipError_t launched = enqueue();
+    const hipError_t recorded = hipEventRecord(ev.stop, stream);
+    const hipError_t waited = hipEventSynchronize(ev.stop);
+    if (launched != hipSuccess || recorded != hipSuccess || waited != hipSuccess ||
+        hipGetLastError() != hipSuccess) {
+        return code(SpMVError::KERNEL_LAUNCH);
+    }
+    if (hipEventElapsedTime(elapsed_ms, ev.start, ev.stop) != hipSuccess) {
+        return code(SpMVError::KERNEL_LAUNCH);
+    }
+    return code(SpMVError::SUCCESS);
+}
+
+} // namespace
+} // namespace detail
+
+void spmv_set_stream(hipStream_t stream) { detail::g_stream = stream; }
+hipStream_t spmv_get_stream() { return detail::g_stream; }
+
+SpMVResult spmv_csr(const CSRMatrix* A, const float* d_x, float* d_y,
+                    const SpMVConfig* config, int vec_size) {
+    SpMVResult result;
+    bool nothing = false;
+    result.error_code = detail::check_csr(A, d_x, d_y, vec_size, &nothing);
+    if (result.error_code != 0) return result;
+    if (nothing) {
+        result.y = d_y;
+        return result;
+    }
+
+    const SpMVConfig fallback;
+    if (!config) config = &fallback;
+    if (!detail::block_size_ok(config)) {
+        result.error_code = detail::code(SpMVError::KERNEL_LAUNCH);
+        return result;
+    }
+
+    hipStream_t stream = detail::current_stream();
+    result.error_code = detail::timed(stream, &result.elapsed_ms, [&] {
+        return detail::enqueue_csr(A, d_x, d_y, config, stream);
+    });
+    if (result.error_code != 0) return result;
+
+    if (result.elapsed_ms > 0.0f) {
+        result.gflops = (2.0f * A->nnz) / (result.elapsed_ms * 1e6f);
+    }
+    result.bandwidth_gb_s = compute_bandwidth_csr(A, result.elapsed_ms).achieved_bandwidth_gb_s;
+    result.y = d_y;
+    return result;
+}
+
+int spmv_csr_async(const CSRMatrix* A, const float* d_x, float* d_y,
+                   const SpMVConfig* config, int vec_size, hipStream_t stream) {
+    bool nothing = false;
+    const int status = detail::check_csr(A, d_x, d_y, vec_size, &nothing);
+    if (status != 0 || nothing) return status;
+    const SpMVConfig fallback;
+    if (!config) config = &fallback;
+    if (!detail::block_size_ok(config)) return detail::code(SpMVError::KERNEL_LAUNCH);
+    return detail::enqueue_csr(A, d_x, d_y, config, stream) == hipSuccess
+         ? detail::code(SpMVError::SUCCESS) : detail::code(SpMVError::KERNEL_LAUNCH);
+}
+
+SpMVResult spmv_ell(const ELLMatrix* A, const float* d_x, float* d_y,
+                    const SpMVConfig* config, int vec_size) {
+    SpMVResult result;
+    bool nothing = false;
+    result.error_code = detail::check_ell(A, d_x, d_y, vec_size, &nothing);
+    if (result.error_code != 0) return result;
+    if (nothing) {
+        result.y = d_y;
+        return result;
+    }
+
+    const SpMVConfig fallback;
+    if (!config) config = &fallback;
+    if (!detail::block_size_ok(config)) {
+        result.error_code = detail::code(SpMVError::KERNEL_LAUNCH);
+        return result;
+    }
+
+    hipStream_t stream = detail::current_stream();
+    result.error_code = detail::timed(stream, &result.elapsed_ms, [&] {
+        return detail::enqueue_ell(A, d_x, d_y, stream);
+    });
+    if (result.error_code != 0) return result;
+
+    // gflops counts stored entries only (padding excluded), counted once per matrix
+    long long stored = 0;
+    if (A->d_col_indices) {
+        detail::EllAux* aux = detail::ell_aux_lookup(A->d_col_indices, true);
+        if (!aux->have_nnz) {
+            if (detail::device_count_ell_nnz(A, &aux->actual_nnz, stream) == hipSuccess) {
+                aux->have_nnz = true;
+            }
+        }
+        stored = aux->actual_nnz;
+    }
+    if (result.elapsed_ms > 0.0f) {
+        result.gflops = (2.0f * static_cast<float>(stored)) / (result.elapsed_ms * 1e6f);
+    }
+    result.bandwidth_gb_s = compute_bandwidth_ell(A, result.elapsed_ms).achieved_bandwidth_gb_s;
+    result.y = d_y;
+    return result;
+}
+
+int spmv_ell_async(const ELLMatrix* A, const float* d_x, float* d_y,
+                   const SpMVConfig* config, int vec_size, hipStream_t stream) {
+    bool nothing = false;
+    const int status = detail::check_ell(A, d_x, d_y, vec_size, &nothing);
+    if (status != 0 || nothing) return status;
+    const SpMVConfig fallback;
+    if (!config) config = &fallback;
+    if (!detail::block_size_ok(config)) return detail::code(SpMVError::KERNEL_LAUNCH);
+    return detail::enqueue_ell(A, d_x, d_y, stream) == hipSuccess
+         ? detail::code(SpMVError::SUCCESS) : detail::code(SpMVError::KERNEL_LAUNCH);
+}
+
+} // namespace spmv

@@ -1,0 +1,246 @@
+/* spmv_c.h — C-ABI boundary of the MI355X-native SpMV library (libspmv_amd.so).
+ *
+ * The reference (LessUp/gpu-spmv) is a C++ library: free functions in
+ * `namespace spmv` over plain structs (its include/spmv headers).  This header exports
+ * the same entry points with C linkage — plain pointers, sizes and POD structs,
+ * no C++ or torch types — so any FFI (ctypes, cgo, JNI, N-API) can bind them.
+ * Every struct below has the byte layout of the reference's C++ struct of the
+ * same name (x86-64 SysV), so a `spmv::CSRMatrix*` and a `spmv_c_csr*` are
+ * interchangeable.  Each declaration cites the reference interface it replaces.
+ *
+ * Functions that return `int` return a spmv error code (0 = success, negative
+ * values as reference include/spmv/common.h:13-23).  Results that the C++ API
+ * returns by value come back through an `out` pointer.
+ * Device pointers (`d_*`) are addresses in the current HIP device's memory.
+ */
+#ifndef SPMV_C_H
+#define SPMV_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: reference include/spmv/common.h:13-23 ---- */
+enum {
+    SPMV_C_SUCCESS = 0,
+    SPMV_C_INVALID_DIMENSION = -1,
+    SPMV_C_DEVICE_MALLOC = -2,
+    SPMV_C_DEVICE_MEMCPY = -3,
+    SPMV_C_KERNEL_LAUNCH = -4,
+    SPMV_C_INVALID_FORMAT = -5,
+    SPMV_C_FILE_IO = -6,
+    SPMV_C_OUT_OF_MEMORY = -7,
+    SPMV_C_INVALID_ARGUMENT = -8
+};
+/* reference include/spmv/common.h:26-39 (spmv_error_string) */
+const char* spmv_c_error_string(int code);
+
+/* ---- structs ---- */
+
+/* reference include/spmv/csr_matrix.h:11-28 (72 bytes) */
+typedef struct spmv_c_csr {
+    int32_t num_rows, num_cols, nnz;
+    float*   values;
+    int32_t* col_indices;
+    int32_t* row_ptrs;
+    float*   d_values;
+    int32_t* d_col_indices;
+    int32_t* d_row_ptrs;
+    uint8_t  owns_host_memory;
+    uint8_t  owns_device_memory;
+} spmv_c_csr;
+
+/* reference include/spmv/ell_matrix.h:12-28 (56 bytes) */
+typedef struct spmv_c_ell {
+    int32_t num_rows, num_cols, max_nnz_per_row;
+    float*   values;
+    int32_t* col_indices;
+    float*   d_values;
+    int32_t* d_col_indices;
+    uint8_t  owns_host_memory;
+    uint8_t  owns_device_memory;
+} spmv_c_ell;
+
+/* reference include/spmv/csr_matrix.h:64-69 */
+typedef struct spmv_c_csr_stats {
+    float   avg_nnz_per_row;
+    int32_t max_nnz_per_row;
+    int32_t min_nnz_per_row;
+    float   skewness;
+} spmv_c_csr_stats;
+
+/* reference include/spmv/spmv.h:11-24; kernel_type: 0 SCALAR_CSR, 1 VECTOR_CSR,
+ * 2 MERGE_PATH, 3 ELL_KERNEL (12 bytes) */
+typedef struct spmv_c_config {
+    int32_t kernel_type;
+    int32_t block_size;
+    uint8_t use_texture;
+} spmv_c_config;
+
+/* reference include/spmv/spmv.h:27-36 (24 bytes) */
+typedef struct spmv_c_result {
+    float*  y;
+    float   elapsed_ms;
+    float   gflops;
+    float   bandwidth_gb_s;
+    int32_t error_code;
+} spmv_c_result;
+
+/* reference include/spmv/bandwidth.h:10-18 */
+typedef struct spmv_c_bandwidth {
+    float theoretical_bandwidth_gb_s;
+    float achieved_bandwidth_gb_s;
+    float efficiency;
+} spmv_c_bandwidth;
+
+/* reference include/spmv/pagerank.h:9-15 */
+typedef struct spmv_c_pagerank_config {
+    float   damping_factor;
+    float   tolerance;
+    int32_t max_iterations;
+} spmv_c_pagerank_config;
+
+/* reference include/spmv/pagerank.h:18-25 (24 bytes) */
+typedef struct spmv_c_pagerank_result {
+    float*  ranks;
+    int32_t iterations;
+    float   final_residual;
+    uint8_t converged;
+} spmv_c_pagerank_result;
+
+/* reference include/spmv/pagerank.h:38-41 */
+typedef struct spmv_c_topk_node {
+    int32_t node_id;
+    float   rank;
+} spmv_c_topk_node;
+
+/* ---- library / device ---- */
+const char* spmv_c_version(void);
+int spmv_c_device_count(void);                       /* 0 when no HIP device is visible */
+int spmv_c_device_name(char* buf, size_t buf_len);   /* gcnArchName of the current device */
+int spmv_c_set_device(int ordinal);
+/* stream used by the synchronous entry points of the calling thread (NULL = null stream) */
+void spmv_c_set_stream(void* hip_stream);
+
+/* ---- device buffers: reference include/spmv/cuda_buffer.h:12-101 (CudaBuffer<T>) ---- */
+int spmv_c_device_malloc(void** d_ptr, size_t bytes);            /* ctor / resize */
+int spmv_c_device_free(void* d_ptr);                             /* dtor / release */
+int spmv_c_memcpy_h2d(void* d_dst, const void* src, size_t bytes);   /* copyFromHost */
+int spmv_c_memcpy_d2h(void* dst, const void* d_src, size_t bytes);   /* copyToHost */
+int spmv_c_device_synchronize(void);
+
+/* ---- CSR container: reference include/spmv/csr_matrix.h:31-71 ---- */
+spmv_c_csr* spmv_c_csr_create(int rows, int cols, int nnz);
+void spmv_c_csr_destroy(spmv_c_csr* mat);
+int spmv_c_csr_from_dense(spmv_c_csr* csr, const float* dense, int rows, int cols);
+int spmv_c_csr_to_dense(const spmv_c_csr* csr, float* dense);
+float spmv_c_csr_get_element(const spmv_c_csr* mat, int row, int col);
+int spmv_c_csr_to_gpu(spmv_c_csr* mat);
+int spmv_c_csr_from_gpu(spmv_c_csr* mat);
+void spmv_c_csr_free_gpu(spmv_c_csr* mat);
+int spmv_c_csr_serialize(const spmv_c_csr* mat, const char* filename);
+int spmv_c_csr_deserialize(spmv_c_csr* mat, const char* filename);
+int spmv_c_csr_compute_stats(const spmv_c_csr* mat, spmv_c_csr_stats* out);
+/* extension: a matrix header over device arrays the caller owns (no host arrays) */
+spmv_c_csr* spmv_c_csr_wrap_device(int rows, int cols, int nnz, const int32_t* d_row_ptrs,
+                                   const int32_t* d_col_indices, const float* d_values);
+
+/* ---- ELL container: reference include/spmv/ell_matrix.h:31-66 ---- */
+spmv_c_ell* spmv_c_ell_create(int rows, int cols, int max_nnz_per_row);
+void spmv_c_ell_destroy(spmv_c_ell* mat);
+int spmv_c_ell_from_dense(spmv_c_ell* ell, const float* dense, int rows, int cols);
+int spmv_c_ell_from_csr(spmv_c_ell* ell, const spmv_c_csr* csr);
+int spmv_c_ell_to_dense(const spmv_c_ell* ell, float* dense);
+float spmv_c_ell_get_element(const spmv_c_ell* mat, int row, int col);
+int spmv_c_ell_to_gpu(spmv_c_ell* mat);
+int spmv_c_ell_from_gpu(spmv_c_ell* mat);
+void spmv_c_ell_free_gpu(spmv_c_ell* mat);
+int spmv_c_ell_serialize(const spmv_c_ell* mat, const char* filename);
+int spmv_c_ell_deserialize(spmv_c_ell* mat, const char* filename);
+int spmv_c_ell_index(int row, int k, int num_rows);
+spmv_c_ell* spmv_c_ell_wrap_device(int rows, int cols, int max_nnz_per_row,
+                                   const int32_t* d_col_indices, const float* d_values);
+
+/* ---- SpMV: reference include/spmv/spmv.h:39-54 ---- */
+void spmv_c_cpu_csr(const spmv_c_csr* A, const float* x, float* y);      /* spmv_cpu_csr */
+void spmv_c_cpu_ell(const spmv_c_ell* A, const float* x, float* y);      /* spmv_cpu_ell */
+/* spmv_csr / spmv_ell: config may be NULL (defaults), vec_size < 0 skips the size check;
+ * the return value equals out->error_code */
+int spmv_c_spmv_csr(const spmv_c_csr* A, const float* d_x, float* d_y,
+                    const spmv_c_config* config, int vec_size, spmv_c_result* out);
+int spmv_c_spmv_ell(const spmv_c_ell* A, const float* d_x, float* d_y,
+                    const spmv_c_config* config, int vec_size, spmv_c_result* out);
+int spmv_c_auto_config(const spmv_c_csr* A, spmv_c_config* out);          /* spmv_auto_config */
+int spmv_c_validate_dimensions(int num_cols, int vec_size);               /* 1 = match */
+/* extension: enqueue on a caller stream without timing or synchronisation */
+int spmv_c_spmv_csr_async(const spmv_c_csr* A, const float* d_x, float* d_y,
+                          const spmv_c_config* config, int vec_size, void* hip_stream);
+int spmv_c_spmv_ell_async(const spmv_c_ell* A, const float* d_x, float* d_y,
+                          const spmv_c_config* config, int vec_size, void* hip_stream);
+
+/* ---- bandwidth model: reference include/spmv/bandwidth.h:21-27 ---- */
+int spmv_c_compute_bandwidth_csr(const spmv_c_csr* A, float elapsed_ms, spmv_c_bandwidth* out);
+int spmv_c_compute_bandwidth_ell(const spmv_c_ell* A, float elapsed_ms, spmv_c_bandwidth* out);
+float spmv_c_get_gpu_peak_bandwidth(void);
+
+/* ---- PageRank: reference include/spmv/pagerank.h:29-43 ---- */
+int spmv_c_pagerank(const spmv_c_csr* adj, const spmv_c_pagerank_config* config,
+                    spmv_c_pagerank_result* out);
+void spmv_c_pagerank_free(spmv_c_pagerank_result* result);
+void spmv_c_pagerank_top_k(const spmv_c_pagerank_result* result, int num_nodes, int k,
+                           spmv_c_topk_node* top_k);
+
+/* ---- PageRank shard engine (extension: the row-sharded multi-GPU loop) ----
+ * One rank owns rows [row_offset, row_offset + A_local->num_rows) of the
+ * n_global x n_global matrix (A_local: device CSR, row_ptrs rebased to 0,
+ * num_cols = n_global) and full-length device vectors.  Per iteration the host
+ * calls step -> reduce -> [all-reduce d_sums over ranks] -> commit ->
+ * [all-gather the new slice].  All calls enqueue on `hip_stream` and return. */
+typedef struct spmv_c_pr_shard spmv_c_pr_shard;   /* opaque */
+typedef struct spmv_c_pr_status {                 /* device-side state, copied out */
+    float   dangling_sum;
+    float   final_residual;
+    int32_t iterations;
+    int32_t converged;
+    int32_t done;
+    int32_t reserved;
+} spmv_c_pr_status;
+
+spmv_c_pr_shard* spmv_c_pr_shard_create(const spmv_c_csr* A_local, int row_offset, int n_global,
+                                        const uint8_t* d_dangling_mask);
+void spmv_c_pr_shard_destroy(spmv_c_pr_shard* shard);
+/* resets the iteration state; dangling_sum = dangling mass of the start vector */
+int spmv_c_pr_reset(spmv_c_pr_shard* shard, float dangling_sum, void* hip_stream);
+int spmv_c_pr_step(spmv_c_pr_shard* shard, const float* d_r_old, float* d_r_new, float damping,
+                   void* hip_stream);
+int spmv_c_pr_reduce(spmv_c_pr_shard* shard, double* d_sums /*[2]*/, void* hip_stream);
+int spmv_c_pr_commit(spmv_c_pr_shard* shard, const double* d_sums, float tolerance, void* hip_stream);
+int spmv_c_pr_status_get(spmv_c_pr_shard* shard, spmv_c_pr_status* out, void* hip_stream); /* syncs */
+/* dangling-node detection on the device: accumulate this shard's column sums
+ * (atomic adds into d_col_sums[n_global]); after the sums of all shards are
+ * combined, mask[c] = (sum == 0). */
+int spmv_c_pr_column_sums(const spmv_c_csr* A_local, float* d_col_sums, void* hip_stream);
+int spmv_c_pr_mask_from_column_sums(const float* d_col_sums, int n, uint8_t* d_mask,
+                                    uint64_t* d_count, void* hip_stream);
+int spmv_c_fill(float* d_r, size_t n, float value, void* hip_stream);
+
+/* ---- synthetic inputs generated in HBM (extension; numpy twin: gpu-spmv_amd/synth.py) ---- */
+int spmv_c_gen_uniform_rows(uint64_t seed, int row_begin, int local_rows, int n_cols, int k,
+                            int32_t* d_row_ptrs, int32_t* d_cols, float* d_vals, void* hip_stream);
+int spmv_c_gen_stratified_rows(uint64_t seed, int row_begin, int local_rows, int n_cols,
+                               const int32_t* d_row_ptrs, int32_t* d_cols, float* d_vals,
+                               void* hip_stream);
+int spmv_c_gen_vector(uint64_t seed, uint64_t tag, size_t n, float* d_x, void* hip_stream);
+int spmv_c_count_columns(int64_t nnz, const int32_t* d_cols, int n_cols, int32_t* d_counts,
+                         void* hip_stream);
+int spmv_c_reciprocal_values(int64_t nnz, const int32_t* d_cols, const int32_t* d_counts,
+                             float* d_vals, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SPMV_C_H */

@@ -1,0 +1,220 @@
+"""GPU parity tests: every SpMV kernel, called through the C ABI, against the CPU
+oracle on the same inputs.  Tolerances: SCALAR_CSR and ELL reproduce the CPU's
+summation order with unfused multiply/add and are held to bit equality;
+VECTOR_CSR and MERGE_PATH reorder the sum and are held to 1e-5 relative
+(BASELINE.json north_star; comparator shape of reference tests/test_spmv.cu:18-35)."""
+import numpy as np
+import pytest
+
+from conftest import max_rel_err, random_dense
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = {"scalar": 0, "vector": 1, "merge": 2}
+REORDER_TOL = 1e-5
+
+
+def run_csr(spmv, row_ptrs, cols, vals, num_cols, x, kernel, vec_size=None):
+    A = spmv.csr_from_arrays(len(row_ptrs) - 1, num_cols, row_ptrs, cols, vals)
+    try:
+        assert spmv.csr_to_gpu(A) == 0
+        d_x = spmv.CudaBuffer(max(num_cols, 1))
+        d_y = spmv.CudaBuffer(max(len(row_ptrs) - 1, 1))
+        d_x.copyFromHost(x, len(x))
+        cfg = spmv.SpMVConfig(kernel_type=kernel)
+        res = spmv.spmv_csr(A, d_x, d_y, cfg, num_cols if vec_size is None else vec_size)
+        assert res.error_code == 0, spmv.spmv_error_string(res.error_code)
+        return d_y.copyToHost(len(row_ptrs) - 1), res
+    finally:
+        spmv.csr_destroy(A)
+
+
+def check(spmv, oracle, row_ptrs, cols, vals, num_cols, x, kernels=KERNELS):
+    want = oracle.spmv_csr(row_ptrs, cols, vals, x)
+    for name, kt in kernels.items():
+        got, _ = run_csr(spmv, row_ptrs, cols, vals, num_cols, x, kt)
+        if name == "scalar":
+            np.testing.assert_array_equal(got, want, err_msg=name)
+        else:
+            assert max_rel_err(want, got) <= REORDER_TOL, name
+
+
+def test_property_random_dense_matrices(gpu, oracle):
+    """reference tests/test_spmv.cu:40-78 (P8), widened to all three CSR kernels."""
+    rng = np.random.default_rng(42)
+    for _ in range(40):
+        rows, cols = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        dense = random_dense(rng, rows, cols, rng.uniform(0.01, 0.3))
+        x = rng.uniform(-10, 10, cols).astype(np.float32)
+        rp, ci, va = oracle.csr_from_dense(dense)
+        if ci.size == 0:
+            continue
+        check(gpu, oracle, rp, ci, va, cols, x)
+
+
+@pytest.mark.parametrize("rows,cols,k", [(1000, 1000, 8), (4097, 5000, 16), (3000, 70000, 3),
+                                         (777, 900, 33), (2048, 2048, 64), (5, 40, 1)])
+def test_uniform_rows(gpu, oracle, rows, cols, k):
+    rp, ci, va = gpu.synth.uniform_csr(42, 0, rows, cols, k)
+    x = gpu.synth.vector(42, 7, cols)
+    check(gpu, oracle, rp, ci, va, cols, x)
+
+
+def test_power_law_rows_with_empty_rows(gpu, oracle):
+    lens = gpu.synth.power_law_lengths(42, 20000, max_len=5000, n_cols=30000)
+    lens[::7] = 0                       # sprinkle empty rows
+    lens[0] = 0
+    lens[-1] = 0
+    rp, ci, va = gpu.synth.stratified_csr(42, 0, lens, 30000)
+    x = gpu.synth.vector(42, 1, 30000)
+    check(gpu, oracle, rp, ci, va, 30000, x)
+
+
+def test_ragged_lengths_not_multiple_of_four(gpu, oracle):
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 23, size=5001)
+    rp, ci, va = gpu.synth.stratified_csr(5, 0, lens, 4000)
+    x = gpu.synth.vector(5, 2, 4000)
+    check(gpu, oracle, rp, ci, va, 4000, x)
+
+
+def test_single_long_row_and_single_row(gpu, oracle):
+    lens = np.array([50000], dtype=np.int64)
+    rp, ci, va = gpu.synth.stratified_csr(9, 0, lens, 60000)
+    x = gpu.synth.vector(9, 3, 60000)
+    check(gpu, oracle, rp, ci, va, 60000, x)
+    lens = np.array([3, 0, 40000, 1, 0, 0, 9], dtype=np.int64)
+    rp, ci, va = gpu.synth.stratified_csr(9, 0, lens, 60000)
+    check(gpu, oracle, rp, ci, va, 60000, x)
+
+
+def test_known_answers_from_reference_tests(gpu, oracle):
+    """tests/test_spmv.cu:161-186 (5*2 = 10) and :188-218 ({3,0,7}); README.md:75-99 ({3,7,5})."""
+    for dense, x, want in [
+        (np.array([[5.0]], np.float32), np.array([2.0], np.float32), [10.0]),
+        (np.array([[1, 2, 0], [0, 0, 0], [3, 0, 4]], np.float32), np.ones(3, np.float32), [3.0, 0.0, 7.0]),
+        (np.array([[1, 0, 2], [0, 3, 4], [5, 0, 0]], np.float32), np.ones(3, np.float32), [3.0, 7.0, 5.0]),
+    ]:
+        rp, ci, va = oracle.csr_from_dense(dense)
+        for kt in KERNELS.values():
+            got, _ = run_csr(gpu, rp, ci, va, dense.shape[1], x, kt)
+            np.testing.assert_array_equal(got, np.array(want, np.float32))
+
+
+def test_default_config_and_ell_kernel_enum_fall_back_to_scalar(gpu, oracle):
+    """nullptr config => SCALAR_CSR; ELL_KERNEL passed to spmv_csr behaves as scalar
+    (reference src/spmv_kernels.cu:234-237, :287-288)."""
+    rp, ci, va = gpu.synth.uniform_csr(1, 0, 300, 300, 5)
+    x = gpu.synth.vector(1, 0, 300)
+    want = oracle.spmv_csr(rp, ci, va, x)
+    A = gpu.csr_from_arrays(300, 300, rp, ci, va)
+    gpu.csr_to_gpu(A)
+    d_x, d_y = gpu.CudaBuffer(300), gpu.CudaBuffer(300)
+    d_x.copyFromHost(x, 300)
+    res = gpu.spmv_csr(A, d_x, d_y, None, -1)          # vec_size = -1 skips the size check
+    assert res.error_code == 0 and res.y == d_y.get()
+    np.testing.assert_array_equal(d_y.copyToHost(300), want)
+    res = gpu.spmv_csr(A, d_x, d_y, gpu.SpMVConfig(kernel_type=gpu.SpMVConfig.ELL_KERNEL), 300)
+    assert res.error_code == 0
+    np.testing.assert_array_equal(d_y.copyToHost(300), want)
+    assert res.elapsed_ms > 0 and res.gflops > 0 and res.bandwidth_gb_s > 0
+    gpu.csr_destroy(A)
+
+
+def test_error_codes_in_reference_order(gpu):
+    """null args -> -8; size mismatch -> -1; missing device arrays -> -5
+    (reference src/spmv_kernels.cu:219-232)."""
+    rp, ci, va = gpu.synth.uniform_csr(1, 0, 10, 10, 2)
+    A = gpu.csr_from_arrays(10, 10, rp, ci, va)
+    d = gpu.CudaBuffer(10)
+    assert gpu.spmv_csr(None, d, d, None, 10).error_code == gpu.SpMVError.INVALID_ARGUMENT
+    assert gpu.spmv_csr(A, None, d, None, 10).error_code == gpu.SpMVError.INVALID_ARGUMENT
+    assert gpu.spmv_csr(A, d, d, None, 11).error_code == gpu.SpMVError.INVALID_DIMENSION
+    assert gpu.spmv_csr(A, d, d, None, 10).error_code == gpu.SpMVError.INVALID_FORMAT   # not uploaded
+    gpu.csr_destroy(A)
+
+
+def test_empty_and_all_zero_matrices(gpu):
+    """0x0 matrix is a successful no-op (reference tests/test_spmv.cu:148-159 expects it);
+    nnz == 0 with rows > 0 succeeds with y = 0 (SURVEY.md D2/D3 deviations)."""
+    A = gpu.csr_create(0, 0, 0)
+    gpu.csr_to_gpu(A)
+    d = gpu.CudaBuffer(1)
+    assert gpu.spmv_csr(A, d, d, None, 1).error_code == 0
+    gpu.csr_destroy(A)
+
+    A = gpu.csr_create(3, 3, 0)
+    assert gpu.csr_to_gpu(A) == 0
+    d_x, d_y = gpu.CudaBuffer(3), gpu.CudaBuffer(3)
+    d_x.copyFromHost(np.ones(3, np.float32), 3)
+    d_y.copyFromHost(np.full(3, 9.0, np.float32), 3)
+    for kt in KERNELS.values():
+        assert gpu.spmv_csr(A, d_x, d_y, gpu.SpMVConfig(kernel_type=kt), 3).error_code == 0
+        np.testing.assert_array_equal(d_y.copyToHost(3), np.zeros(3, np.float32))
+    gpu.csr_destroy(A)
+
+
+def test_nonfinite_x_outside_row_support_does_not_leak(gpu, oracle):
+    """The 16-byte aligned loads read neighbours' entries; they must be masked by select."""
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 9, size=999)
+    rp, ci, va = gpu.synth.stratified_csr(11, 0, lens, 5000)
+    x = gpu.synth.vector(11, 0, 5000)
+    x[ci[rp[500]:rp[501]]] = np.inf          # only row 500 (and rows sharing its columns) may see inf
+    want = oracle.spmv_csr(rp, ci, va, x)
+    got, _ = run_csr(gpu, rp, ci, va, 5000, x, KERNELS["vector"])
+    finite = np.isfinite(want)
+    np.testing.assert_array_equal(np.isfinite(got), finite)
+    assert max_rel_err(want[finite], got[finite]) <= REORDER_TOL
+
+
+# ---------------------------------------------------------------- ELL ----------------
+def run_ell(spmv, rows, cols, k, ell_cols, ell_vals, x):
+    E = spmv.ell_create(rows, cols, k)
+    import ctypes
+    m = E.contents
+    if rows * k:
+        ctypes.memmove(m.col_indices, ell_cols.ctypes.data, ell_cols.nbytes)
+        ctypes.memmove(m.values, ell_vals.ctypes.data, ell_vals.nbytes)
+    assert spmv.ell_to_gpu(E) == 0
+    d_x, d_y = spmv.CudaBuffer(max(cols, 1)), spmv.CudaBuffer(max(rows, 1))
+    d_x.copyFromHost(x, cols)
+    res = spmv.spmv_ell(E, d_x, d_y, None, cols)
+    assert res.error_code == 0
+    y = d_y.copyToHost(rows)
+    spmv.ell_destroy(E)
+    return y, res
+
+
+@pytest.mark.parametrize("rows,cols,k", [(1000, 1000, 32), (1001, 1200, 7), (4096, 300, 5), (3, 9, 2)])
+def test_ell_matches_oracle_bit_for_bit(gpu, oracle, rows, cols, k):
+    """reference tests/test_spmv.cu:82-118 (P9); ragged rows so padding is exercised."""
+    rng = np.random.default_rng(rows)
+    lens = rng.integers(0, k + 1, size=rows)
+    lens[rng.integers(0, rows)] = k
+    rp, ci, va = gpu.synth.stratified_csr(4, 0, lens, cols)
+    kk, ecols, evals = oracle.ell_from_csr(rp, ci, va)
+    assert kk == k
+    x = gpu.synth.vector(4, 9, cols)
+    want = oracle.spmv_ell(rows, k, ecols, evals, x)
+    got, res = run_ell(gpu, rows, cols, k, ecols, evals, x)
+    np.testing.assert_array_equal(got, want)
+    # gflops counts stored entries only (reference src/spmv_kernels.cu:398-407)
+    assert res.gflops == pytest.approx(2.0 * ci.size / (res.elapsed_ms * 1e6), rel=1e-3)
+
+
+# ------------------------------------------------------- BASELINE full-size properties --
+def test_config2_full_size_linearity_and_oracle(gpu, oracle):
+    """BASELINE config 2 (1M x 1M, 16/row): oracle comparison on the full matrix plus
+    linearity A(ax + by) = aAx + bAy, a size-independent property."""
+    n, k = 1_000_000, 16
+    rp, ci, va = gpu.synth.uniform_csr(42, 0, n, n, k)
+    x1, x2 = gpu.synth.vector(42, 1, n), gpu.synth.vector(42, 2, n)
+    y1, _ = run_csr(gpu, rp, ci, va, n, x1, KERNELS["vector"])
+    assert max_rel_err(oracle.spmv_csr(rp, ci, va, x1), y1) <= REORDER_TOL
+    y2, _ = run_csr(gpu, rp, ci, va, n, x2, KERNELS["vector"])
+    y3, _ = run_csr(gpu, rp, ci, va, n, (2.0 * x1 + 0.5 * x2).astype(np.float32), KERNELS["vector"])
+    lin = 2.0 * y1.astype(np.float64) + 0.5 * y2.astype(np.float64)
+    assert np.max(np.abs(lin - y3)) <= 1e-4 * max(1.0, np.max(np.abs(lin)))
+    ym, _ = run_csr(gpu, rp, ci, va, n, x1, KERNELS["merge"])
+    assert max_rel_err(y1, ym) <= 2 * REORDER_TOL

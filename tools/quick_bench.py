@@ -1,0 +1,43 @@
+"""quick_bench.py — developer probe: times every CSR kernel on the BASELINE configs
+(device-generated inputs) and prints algorithmic GB/s.  Not the contract bench (bench.py)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+spmv = importlib.import_module("gpu-spmv_amd")
+wl = importlib.import_module("gpu-spmv_amd.workloads")
+
+
+def report(name, A, kernels=(0, 1, 2)):
+    x = wl.vector_device(42, 1, A.cols)
+    y = spmv.CudaBuffer(A.rows)
+    bytes_ = A.nnz * 8 + (A.rows + 1) * 4 + A.cols * 4 + A.rows * 4
+    for kt in kernels:
+        t = wl.time_spmv_csr(A, x, y, kt, warmup=3, runs=10)
+        avg, best = float(np.mean(t)), float(np.min(t))
+        print(f"{name:28s} kernel={kt} avg={avg*1e3:9.1f}us min={best*1e3:9.1f}us "
+              f"GB/s={bytes_/avg/1e6:8.1f} frac={bytes_/avg/1e6/8000:.3f} GFLOPS={2*A.nnz/avg/1e6:8.1f}",
+              flush=True)
+    x.release(); y.release()
+
+
+def main():
+    spmv.require_gpu()
+    print(spmv.version(), spmv.device_name(), flush=True)
+    which = sys.argv[1:] or ["c1", "c2", "c4", "c5"]
+    if "c1" in which:
+        A = wl.uniform_csr_device(42, 1000, 1000, 8); report("c1 1k x 8", A); A.close()
+    if "c2" in which:
+        A = wl.uniform_csr_device(42, 1_000_000, 1_000_000, 16); report("c2 1M x 16", A); A.close()
+    if "c4" in which:
+        A = wl.power_law_csr_device(42, 1_000_000, 1_000_000)
+        print("c4 nnz", A.nnz, flush=True); report("c4 1M power-law", A); A.close()
+    if "c5" in which:
+        A = wl.uniform_csr_device(42, 10_000_000, 10_000_000, 16); report("c5 10M x 16", A, kernels=(1, 2)); A.close()
+
+
+if __name__ == "__main__":
+    main()

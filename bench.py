@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py — the contract benchmark.
+
+Workload (BASELINE.json: the matrix the headline metric is quoted on): uniform random
+CSR, 10,000,000 x 10,000,000, exactly 16 entries per row (160 M entries, fp32 values,
+int32 indices, column-stochastic), generated directly in HBM.
+
+A "step" is one pass of the hot path over that matrix: ONE vector-CSR SpMV, run as a
+PageRank power iteration (fused SpMV + damping/teleport update + residual partials,
+then — for N > 1 — the RCCL all-reduce of two scalars and the all-gather of the rank
+slices).  Rows are sharded over the N ranks (strong scaling: total work fixed).
+
+    value = (algorithmic CSR bytes of the WHOLE matrix, reference byte model
+             src/bandwidth.cpp:34-42) x steps / wall time          [GB/s, whole job]
+
+also reported: GFLOPS, PageRank iterations/s, the roofline of the dominant kernel
+(HIP events around the step kernel alone), the drop-in spmv_csr() numbers per kernel
+type for BASELINE configs 2-5 (reference protocol: 5 warm-up + 20 timed calls,
+kernel-only event time), and the CPU baseline (the reference's spmv_cpu_csr on the same
+matrix, one host thread).
+
+usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--nnz-per-row k] [--no-extras]
+       (N > 1: launched by torch.distributed.run, one rank per GPU)
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--rows", type=int, default=10_000_000)
+    p.add_argument("--nnz-per-row", type=int, default=16)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--no-extras", action="store_true", help="skip the per-config spmv_csr table and the CPU baseline")
+    return p.parse_args()
+
+
+def csr_bytes(rows, cols, nnz):
+    return nnz * 8 + (rows + 1) * 4 + cols * 4 + rows * 4
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+
+    spmv = importlib.import_module("gpu-spmv_amd")
+    wl = importlib.import_module("gpu-spmv_amd.workloads")
+    prd = importlib.import_module("gpu-spmv_amd.pagerank_dist")
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the SpMV path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    spmv.lib().spmv_c_set_device(local_rank)
+    spmv.require_gpu()
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    n, k = args.rows, args.nnz_per_row
+    nnz_total = n * k
+    shard_len, row_begin, row_end = prd.shard_bounds(n, world, rank)
+    local_rows = row_end - row_begin
+
+    # ---- build this rank's rows in HBM (torch owns the memory; the C ABI fills it) ----
+    stream = torch.cuda.current_stream().cuda_stream
+    row_ptrs = torch.empty(local_rows + 1, dtype=torch.int32, device=device)
+    cols = torch.empty(max(local_rows * k, 1), dtype=torch.int32, device=device)
+    vals = torch.empty(max(local_rows * k, 1), dtype=torch.float32, device=device)
+    status = spmv.lib().spmv_c_gen_uniform_rows(args.seed, row_begin, local_rows, n, k, row_ptrs.data_ptr(),
+                                                cols.data_ptr(), vals.data_ptr(), stream)
+    assert status == 0, spmv.spmv_error_string(status)
+    counts = torch.zeros(n, dtype=torch.int32, device=device)
+    spmv.lib().spmv_c_count_columns(local_rows * k, cols.data_ptr(), n, counts.data_ptr(), stream)
+    if world > 1:
+        dist.all_reduce(counts)
+    spmv.lib().spmv_c_reciprocal_values(local_rows * k, cols.data_ptr(), counts.data_ptr(), vals.data_ptr(), stream)
+    del counts
+    cols_v, vals_v = cols[: local_rows * k], vals[: local_rows * k]
+
+    engine = prd.HipEngine(row_ptrs, cols_v, vals_v, row_begin, n)
+    pr = prd.ShardedPageRank(engine, n, rank, world).prepare()
+    pr.reset()
+
+    damping, never = 0.85, 0.0          # tolerance 0: the loop never converges, every step does full work
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(args.warmup):
+        pr.iterate(step, damping, never)
+        step += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pr.iterate(step, damping, never)
+        step += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    iters_done = engine.status()[0]
+    assert iters_done == args.warmup + args.steps, (iters_done, args.warmup, args.steps)
+
+    bytes_per_step = csr_bytes(n, n, nnz_total)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = bytes_per_step * args.steps / elapsed / 1e9
+
+    # ---- roofline of the dominant kernel: the fused step kernel alone, HIP events on its stream ----
+    local_bytes = csr_bytes(local_rows, n, local_rows * k)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+    for a, b in ev:
+        a.record()
+        engine._check(spmv.lib().spmv_c_pr_step(engine._shard, pr.r[0].data_ptr(), pr.r[1].data_ptr(), damping,
+                                                engine._stream()), "pr_step")
+        b.record()
+    torch.cuda.synchronize()
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    achieved = local_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get("pr_step_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "pr_step_kernel (fused vector-CSR SpMV + PageRank update)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": local_bytes}
+
+    result = {
+        "metric": "spmv_effective_bandwidth", "value": round(value, 1), "unit": "GB/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (counter-based uniform random CSR generated in HBM, seed %d)" % args.seed,
+        "config": {"workload": "csr_uniform_%dx%d_%d_per_row_pagerank_step" % (n, n, k), "rows": n, "cols": n,
+                   "nnz": nnz_total, "avg_nnz_per_row": k, "kernel": "VECTOR_CSR (fused PageRank step)",
+                   "parallelism": "row-shard x%d%s" % (world, "" if world == 1 else " + RCCL all-reduce(2 f64) + all-gather(%d f32/rank)" % shard_len)},
+        "gflops": round(2.0 * nnz_total * args.steps / elapsed / 1e9, 1),
+        "pagerank_iters_per_sec": round(args.steps / elapsed, 2),
+        "frac_of_hbm_peak_whole_job": round(value / (HBM_PEAK_GBS * world), 4),
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        result["spmv_csr_api"] = api_table(spmv, wl, engine, n, k, args.seed)
+        result["cpu_baseline"] = cpu_baseline(spmv, row_ptrs, cols_v, vals_v, n, nnz_total)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    engine.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+def api_table(spmv, wl, engine, n, k, seed):
+    """Drop-in spmv_csr()/spmv_ell() numbers, reference protocol (5 warm-up + 20 timed, event time)."""
+    table = {}
+
+    def run(name, handle, rows, cols, nnz, kernels):
+        x = wl.vector_device(seed, 1, cols)
+        y = spmv.CudaBuffer(rows)
+        b = csr_bytes(rows, cols, nnz)
+        for kt, label in kernels:
+            t = wl.time_spmv_csr(handle, x, y, kt)
+            avg = float(np.mean(t))
+            table[f"{name}/{label}"] = {"avg_us": round(avg * 1e3, 1), "min_us": round(float(np.min(t)) * 1e3, 1),
+                                        "GBps": round(b / avg / 1e6, 1), "frac": round(b / avg / 1e6 / HBM_PEAK_GBS, 4),
+                                        "gflops": round(2.0 * nnz / avg / 1e6, 1)}
+        x.release()
+        y.release()
+
+    run("c5_10Mx16", engine._A, n, n, n * k, [(1, "vector"), (2, "merge")])
+    A = wl.uniform_csr_device(seed, 1_000_000, 1_000_000, 16)
+    run("c2_1Mx16", A.handle, A.rows, A.cols, A.nnz, [(1, "vector"), (2, "merge"), (0, "scalar")])
+    A.close()
+    P = wl.power_law_csr_device(seed, 1_000_000, 1_000_000)
+    run("c4_1M_powerlaw_nnz%d" % P.nnz, P.handle, P.rows, P.cols, P.nnz, [(2, "merge"), (1, "vector")])
+    P.close()
+    # config 3: ELL 1M x 32 (column-major), built from a uniform CSR on the host side of the C ABI
+    E = wl.uniform_ell_device(seed, 1_000_000, 1_000_000, 32)
+    x = wl.vector_device(seed, 1, 1_000_000)
+    y = spmv.CudaBuffer(1_000_000)
+    t = wl.time_spmv_ell(E, x, y)
+    avg = float(np.mean(t))
+    b = 1_000_000 * 32 * 8 + 1_000_000 * 4 * 2
+    table["c3_ell_1Mx32"] = {"avg_us": round(avg * 1e3, 1), "min_us": round(float(np.min(t)) * 1e3, 1),
+                             "GBps": round(b / avg / 1e6, 1), "frac": round(b / avg / 1e6 / HBM_PEAK_GBS, 4),
+                             "gflops": round(2.0 * 32e6 / avg / 1e6, 1)}
+    E.close()
+    x.release()
+    y.release()
+    return table
+
+
+def cpu_baseline(spmv, row_ptrs, cols, vals, n, nnz):
+    """The reference's CPU path (src/spmv_cpu.cpp:6-16) on the SAME matrix, one host thread:
+    oracle/_ref/ref_cpu (the reference's own sources, kind "reference") when it was shipped,
+    else the plain-C restatement in oracle/ (kind "port")."""
+    oracle = importlib.import_module("oracle")
+    wl = importlib.import_module("gpu-spmv_amd.workloads")
+    rp, ci, va = row_ptrs.cpu().numpy(), cols.cpu().numpy(), vals.cpu().numpy()
+    x = spmv.synth.vector(42, 1, n)
+    reps = 3
+    if oracle.have_reference_binary():
+        scratch = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        best = oracle.reference_time_csr(rp, ci, va, x, reps=reps, scratch_dir=scratch)
+        kind = "reference"
+    else:
+        oracle.spmv_csr(rp, ci, va, x)
+        best = 1e30
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            oracle.spmv_csr(rp, ci, va, x)
+            best = min(best, time.perf_counter() - t0)
+        kind = "port"
+    b = csr_bytes(n, n, nnz)
+    return {"value": round(b / best / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": kind,
+            "gflops": round(2.0 * nnz / best / 1e9, 3), "seconds_per_spmv": round(best, 4),
+            "sample": "the full workload matrix (%d rows, %d entries), best of %d single-thread SpMV passes after 1 warm-up"
+                      % (n, nnz, reps),
+            "host_cpus_visible": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

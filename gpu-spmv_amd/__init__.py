@@ -198,6 +198,7 @@ _SIGNATURES = {
     "spmv_c_fill": (c_int, [c_void_p, c_size_t, c_float, c_void_p]),
     "spmv_c_gen_uniform_rows": (c_int, [c_uint64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p]),
+    "spmv_c_gen_uniform_ell": (c_int, [c_uint64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "spmv_c_gen_stratified_rows": (c_int, [c_uint64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                            c_void_p]),
     "spmv_c_gen_vector": (c_int, [c_uint64, c_uint64, c_size_t, c_void_p, c_void_p]),

@@ -377,6 +377,11 @@ int spmv_c_gen_uniform_rows(uint64_t seed, int row_begin, int local_rows, int n_
                                     d_vals, as_stream(hip_stream));
 }
 
+int spmv_c_gen_uniform_ell(uint64_t seed, int rows, int n_cols, int k, int32_t* d_cols, float* d_vals,
+                           void* hip_stream) {
+    return detail::gen_uniform_ell(seed, rows, n_cols, k, d_cols, d_vals, as_stream(hip_stream));
+}
+
 int spmv_c_gen_stratified_rows(uint64_t seed, int row_begin, int local_rows, int n_cols,
                                const int32_t* d_row_ptrs, int32_t* d_cols, float* d_vals,
                                void* hip_stream) {

@@ -9,6 +9,8 @@ namespace detail {
 
 int gen_uniform_rows(unsigned long long seed, int row_begin, int local_rows, int n_cols, int k,
                      int* d_row_ptrs, int* d_cols, float* d_vals, hipStream_t s);
+int gen_uniform_ell(unsigned long long seed, int rows, int n_cols, int k, int* d_cols, float* d_vals,
+                    hipStream_t s);
 int gen_stratified_rows(unsigned long long seed, int row_begin, int local_rows, int n_cols,
                         const int* d_row_ptrs, int* d_cols, float* d_vals, hipStream_t s);
 int gen_vector(unsigned long long seed, unsigned long long tag, size_t n, float* d_x, hipStream_t s);

@@ -52,13 +52,15 @@ constexpr unsigned long long kStreamCols = 1, kStreamVals = 2, kStreamVec = 3;
 
 // Exactly k entries per row; the column set is a uniform random k-subset of
 // [0, n_cols): draw k values in [0, n_cols - k], sort, add the rank.
+// ELL = true stores the same entries column-major (slot (r, s) at s * local_rows + r).
+template <bool ELL>
 __global__ __launch_bounds__(kBlock)
 void uniform_rows_kernel(unsigned long long seed, int row_begin, int local_rows, int n_cols, int k,
                          int* __restrict__ row_ptrs, int* __restrict__ cols,
                          float* __restrict__ vals) {
     const long long r = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x;
     if (r > local_rows) return;
-    row_ptrs[r] = static_cast<int>(r * k);
+    if (!ELL) row_ptrs[r] = static_cast<int>(r * k);
     if (r == local_rows) return;
 
     const unsigned long long row = static_cast<unsigned long long>(row_begin) + r;
@@ -73,10 +75,10 @@ void uniform_rows_kernel(unsigned long long seed, int row_begin, int local_rows,
         }
         picks[pos] = v;
     }
-    const long long base = r * k;
     for (int s = 0; s < k; ++s) {
-        cols[base + s] = static_cast<int>(picks[s]) + s;
-        vals[base + s] = to_unit(draw(seed, kStreamVals, row, s));
+        const long long at = ELL ? static_cast<long long>(s) * local_rows + r : r * k + s;
+        cols[at] = static_cast<int>(picks[s]) + s;
+        vals[at] = to_unit(draw(seed, kStreamVals, row, s));
     }
 }
 
@@ -145,8 +147,20 @@ int gen_uniform_rows(unsigned long long seed, int row_begin, int local_rows, int
         return code(SpMVError::INVALID_ARGUMENT);
     }
     const int grid = static_cast<int>((static_cast<long long>(local_rows) + 1 + kBlock - 1) / kBlock);
-    uniform_rows_kernel<<<grid, kBlock, 0, s>>>(seed, row_begin, local_rows, n_cols, k,
-                                                d_row_ptrs, d_cols, d_vals);
+    uniform_rows_kernel<false><<<grid, kBlock, 0, s>>>(seed, row_begin, local_rows, n_cols, k,
+                                                       d_row_ptrs, d_cols, d_vals);
+    return hipGetLastError() == hipSuccess ? 0 : code(SpMVError::KERNEL_LAUNCH);
+}
+
+int gen_uniform_ell(unsigned long long seed, int rows, int n_cols, int k, int* d_cols, float* d_vals,
+                    hipStream_t s) {
+    if (rows < 0 || k < 0 || k > kMaxUniformK || k > n_cols ||
+        (static_cast<long long>(rows) * k > 0 && (!d_cols || !d_vals))) {
+        return code(SpMVError::INVALID_ARGUMENT);
+    }
+    if (rows == 0 || k == 0) return 0;
+    const int grid = static_cast<int>((static_cast<long long>(rows) + kBlock - 1) / kBlock);
+    uniform_rows_kernel<true><<<grid, kBlock, 0, s>>>(seed, 0, rows, n_cols, k, nullptr, d_cols, d_vals);
     return hipGetLastError() == hipSuccess ? 0 : code(SpMVError::KERNEL_LAUNCH);
 }
 

@@ -8,7 +8,8 @@ from ctypes import byref, c_void_p
 
 import numpy as np
 
-from . import CudaBuffer, SpMVConfig, csr_destroy, csr_wrap_device, lib, spmv_csr, synth
+from . import (CudaBuffer, SpMVConfig, csr_destroy, csr_wrap_device, ell_destroy, ell_wrap_device, lib,
+               spmv_csr, spmv_ell, synth)
 
 
 class DeviceCSR:
@@ -99,5 +100,44 @@ def time_spmv_csr(A, d_x, d_y, kernel_type, warmup=5, runs=20):
     for _ in range(runs):
         r = spmv_csr(handle, d_x, d_y, cfg, cols)
         _check(r.error_code, "spmv_csr")
+        times.append(float(r.elapsed_ms))
+    return times
+
+
+class DeviceELL:
+    """Column-major ELL slabs that live only in HBM."""
+
+    def __init__(self, rows, cols, k):
+        self.rows, self.cols, self.k = rows, cols, k
+        self.col_indices = CudaBuffer(max(rows * k, 1), "int32")
+        self.values = CudaBuffer(max(rows * k, 1), "float32")
+        self.handle = ell_wrap_device(rows, cols, k, self.col_indices.get(), self.values.get())
+
+    def close(self):
+        if self.handle is not None:
+            ell_destroy(self.handle)
+            self.handle = None
+        self.col_indices.release()
+        self.values.release()
+
+
+def uniform_ell_device(seed, n_rows, n_cols, k, stream=None) -> DeviceELL:
+    """BASELINE config 3: fixed k entries per row, no padding, column-major (== ell_from_csr of uniform_csr)."""
+    E = DeviceELL(n_rows, n_cols, k)
+    _check(lib().spmv_c_gen_uniform_ell(seed, n_rows, n_cols, k, E.col_indices.get(), E.values.get(),
+                                        c_void_p(stream)), "gen_uniform_ell")
+    lib().spmv_c_device_synchronize()
+    return E
+
+
+def time_spmv_ell(E, d_x, d_y, warmup=5, runs=20):
+    handle = E.handle if isinstance(E, DeviceELL) else E
+    cols = handle.contents.num_cols
+    for _ in range(warmup):
+        _check(spmv_ell(handle, d_x, d_y, None, cols).error_code, "spmv_ell")
+    times = []
+    for _ in range(runs):
+        r = spmv_ell(handle, d_x, d_y, None, cols)
+        _check(r.error_code, "spmv_ell")
         times.append(float(r.elapsed_ms))
     return times

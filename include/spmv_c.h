@@ -230,6 +230,9 @@ int spmv_c_fill(float* d_r, size_t n, float value, void* hip_stream);
 /* ---- synthetic inputs generated in HBM (extension; numpy twin: gpu-spmv_amd/synth.py) ---- */
 int spmv_c_gen_uniform_rows(uint64_t seed, int row_begin, int local_rows, int n_cols, int k,
                             int32_t* d_row_ptrs, int32_t* d_cols, float* d_vals, void* hip_stream);
+/* the same entries as gen_uniform_rows(row_begin = 0), stored column-major (ELL, K = k, no padding) */
+int spmv_c_gen_uniform_ell(uint64_t seed, int rows, int n_cols, int k, int32_t* d_cols, float* d_vals,
+                           void* hip_stream);
 int spmv_c_gen_stratified_rows(uint64_t seed, int row_begin, int local_rows, int n_cols,
                                const int32_t* d_row_ptrs, int32_t* d_cols, float* d_vals,
                                void* hip_stream);

@@ -54,3 +54,23 @@ def random_dense(rng, rows, cols, density, lo=-10.0, hi=10.0):
     vals = rng.uniform(lo, hi, size=(rows, cols)).astype(np.float32)
     vals[vals == 0.0] = 1.0
     return np.where(mask, vals, np.float32(0.0)).astype(np.float32)
+
+
+def reorder_err(row_ptrs, cols, vals, x, expected, actual):
+    """Error measure for kernels that reorder a row's sum (VECTOR_CSR, MERGE_PATH, tiled):
+    max over rows of |got - want| / max(|want|, sum_j |a_ij x_j|).  Bounding the error by
+    the row's absolute sum is the standard backward-error scale for a reordered fp32 sum;
+    a row whose terms cancel (|y_i| << sum |a x|) cannot be held to 1e-5 of |y_i| by ANY
+    summation order other than the oracle's own.  For rows without cancellation this is
+    exactly the relative error of the north-star (1e-5)."""
+    row_ptrs = np.asarray(row_ptrs, dtype=np.int64)
+    prod = np.abs(np.asarray(vals, np.float64) * np.asarray(x, np.float64)[np.asarray(cols)])
+    csum = np.concatenate([[0.0], np.cumsum(prod)])
+    abs_sum = csum[row_ptrs[1:]] - csum[row_ptrs[:-1]]
+    expected = np.asarray(expected, np.float64)
+    actual = np.asarray(actual, np.float64)
+    ok_nonfinite = (~np.isfinite(expected)) & ((expected == actual) | (np.isnan(expected) & np.isnan(actual)))
+    scale = np.maximum(np.maximum(np.abs(expected), abs_sum), 1e-30)
+    err = np.where(ok_nonfinite, 0.0, np.abs(expected - actual) / scale)
+    err = np.where(np.isfinite(expected) | ok_nonfinite, err, np.inf)
+    return float(err.max()) if err.size else 0.0

@@ -1,0 +1,132 @@
+"""GPU tests of the boundary plumbing: CudaBuffer, host<->HBM transfer of the
+containers, device generators == numpy twins, bandwidth metrics, benchmark-style runs."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cuda_buffer_semantics(gpu):
+    """reference tests/test_common.cpp:21-98"""
+    b = gpu.CudaBuffer(100)
+    assert b.get() is not None and b.size() == 100 and not b.empty()
+    data = np.arange(100, dtype=np.float32)
+    b.copyFromHost(data, 100)
+    np.testing.assert_array_equal(b.copyToHost(100), data)
+    with pytest.raises(RuntimeError, match="Copy size exceeds buffer size"):
+        b.copyFromHost(np.zeros(101, np.float32), 101)
+    moved = b.move()                                         # move construction
+    assert b.get() is None and b.size() == 0 and moved.size() == 100
+    np.testing.assert_array_equal(moved.copyToHost(100), data)
+    moved.resize(200)                                        # resize discards contents
+    assert moved.size() == 200 and moved.get() is not None
+    moved.resize(200)
+    moved.release()
+    assert moved.get() is None and moved.size() == 0
+    ib = gpu.CudaBuffer(8, "int32")
+    ib.copyFromHost(np.arange(8, dtype=np.int32), 8)
+    np.testing.assert_array_equal(ib.copyToHost(), np.arange(8, dtype=np.int32))
+
+
+def test_csr_and_ell_gpu_round_trip(gpu):
+    """reference tests/test_csr.cpp:153-200 and tests/test_ell.cpp GPUTransfer"""
+    rp, ci, va = gpu.synth.uniform_csr(3, 0, 300, 400, 6)
+    A = gpu.csr_from_arrays(300, 400, rp, ci, va)
+    assert gpu.csr_to_gpu(A) == 0
+    m = A.contents
+    assert m.d_values and m.d_col_indices and m.d_row_ptrs and m.owns_device_memory
+    import ctypes
+    ctypes.memset(m.values, 0, va.nbytes)                    # wipe the host copy, pull it back
+    ctypes.memset(m.col_indices, 0, ci.nbytes)
+    assert gpu.csr_from_gpu(A) == 0
+    rp2, ci2, va2 = gpu.csr_host_arrays(A)
+    np.testing.assert_array_equal(ci2, ci)
+    np.testing.assert_array_equal(va2, va)
+    assert gpu.csr_to_gpu(A) == 0                            # re-upload frees the old arrays first
+    gpu.csr_free_gpu(A)
+    assert not A.contents.d_values and not A.contents.owns_device_memory
+
+    E = gpu.ell_create(0, 0, 0)
+    assert gpu.ell_from_csr(E, A) == 0 and gpu.ell_to_gpu(E) == 0
+    ecols, evals = gpu.ell_host_arrays(E)
+    ctypes.memset(E.contents.values, 0, evals.nbytes)
+    assert gpu.ell_from_gpu(E) == 0
+    np.testing.assert_array_equal(gpu.ell_host_arrays(E)[1], evals)
+    gpu.ell_destroy(E)
+    gpu.csr_destroy(A)
+
+
+def test_device_generators_equal_numpy_twins(gpu):
+    wl = importlib.import_module("gpu-spmv_amd.workloads")
+    A = wl.uniform_csr_device(42, 5000, 77777, 16, row_begin=123)
+    rp, ci, va = A.to_host()
+    hrp, hci, hva = gpu.synth.uniform_csr(42, 123, 5000, 77777, 16)
+    np.testing.assert_array_equal(rp, hrp)
+    np.testing.assert_array_equal(ci, hci)
+    np.testing.assert_array_equal(va.view(np.uint32), hva.view(np.uint32))
+    A.close()
+
+    B = wl.power_law_csr_device(42, 20000, 50000, max_len=3000)
+    rp, ci, va = B.to_host()
+    lens = gpu.synth.power_law_lengths(42, 20000, max_len=3000, n_cols=50000)
+    hrp, hci, hva = gpu.synth.stratified_csr(42, 0, lens, 50000)
+    np.testing.assert_array_equal(rp, hrp)
+    np.testing.assert_array_equal(ci, hci)
+    np.testing.assert_array_equal(va.view(np.uint32), hva.view(np.uint32))
+    wl.make_column_stochastic(B)
+    np.testing.assert_array_equal(B.values.copyToHost(B.nnz).view(np.uint32),
+                                  gpu.synth.column_stochastic_values(hci, 50000).view(np.uint32))
+    B.close()
+
+    x = wl.vector_device(42, 9, 10001)
+    np.testing.assert_array_equal(x.copyToHost(10001).view(np.uint32), gpu.synth.vector(42, 9, 10001).view(np.uint32))
+
+
+def test_device_only_matrix_stats_and_selector(gpu, oracle):
+    """csr_compute_stats / spmv_auto_config on a wrapped device matrix (no host row_ptrs)"""
+    wl = importlib.import_module("gpu-spmv_amd.workloads")
+    B = wl.power_law_csr_device(7, 30000, 40000, max_len=2000)
+    rp, _, _ = B.to_host()
+    st = gpu.csr_compute_stats(B.handle)
+    avg, mx, mn, skew = oracle.csr_stats(rp)
+    assert (st.max_nnz_per_row, st.min_nnz_per_row) == (mx, mn) and st.skewness == pytest.approx(skew)
+    cfg = gpu.spmv_auto_config(B.handle)
+    assert cfg.kernel_type == gpu.SpMVConfig.MERGE_PATH and cfg.use_texture == 1
+    B.close()
+
+
+def test_bandwidth_metrics_properties(gpu):
+    """reference tests/test_bandwidth.cu:19-64 (P12, peak range)"""
+    assert gpu.get_gpu_peak_bandwidth() == 8000.0            # gfx950 table entry
+    rp, ci, va = gpu.synth.uniform_csr(1, 0, 2000, 2000, 8)
+    A = gpu.csr_from_arrays(2000, 2000, rp, ci, va)
+    gpu.csr_to_gpu(A)
+    d_x, d_y = gpu.CudaBuffer(2000), gpu.CudaBuffer(2000)
+    d_x.copyFromHost(np.ones(2000, np.float32), 2000)
+    for kt in (0, 1, 2):
+        res = gpu.spmv_csr(A, d_x, d_y, gpu.SpMVConfig(kernel_type=kt), 2000)
+        m = gpu.compute_bandwidth_csr(A, res.elapsed_ms)
+        assert m.achieved_bandwidth_gb_s >= 0 and m.theoretical_bandwidth_gb_s > 0 and 0 <= m.efficiency <= 1
+        assert res.bandwidth_gb_s == pytest.approx(m.achieved_bandwidth_gb_s, rel=1e-5)
+        assert res.gflops == pytest.approx(2.0 * 16000 / (res.elapsed_ms * 1e6), rel=1e-4)
+    gpu.csr_destroy(A)
+
+
+def test_async_entry_point_on_a_stream(gpu, oracle):
+    torch = pytest.importorskip("torch")
+    rp, ci, va = gpu.synth.uniform_csr(1, 0, 3000, 3000, 9)
+    x = gpu.synth.vector(1, 1, 3000)
+    A = gpu.csr_from_arrays(3000, 3000, rp, ci, va)
+    gpu.csr_to_gpu(A)
+    stream = torch.cuda.Stream()
+    tx = torch.from_numpy(x).cuda()
+    ty = torch.empty(3000, device="cuda")
+    with torch.cuda.stream(stream):
+        for kt in (1, 2, 0):                                 # merge-path builds its tile table on first use
+            assert gpu.spmv_csr_async(A, tx.data_ptr(), ty.data_ptr(), gpu.SpMVConfig(kernel_type=kt), 3000,
+                                      stream.cuda_stream) == 0
+    stream.synchronize()
+    np.testing.assert_array_equal(ty.cpu().numpy(), oracle.spmv_csr(rp, ci, va, x))   # last launch: scalar
+    gpu.csr_destroy(A)

@@ -1,0 +1,179 @@
+"""GPU tests of the device-resident PageRank (C ABI spmv_c_pagerank + the shard engine)
+against the CPU oracle (restatement of reference src/pagerank.cu:50-153).
+Tolerance: the device accumulates the residual / dangling mass / final sum in double and
+reorders each row's SpMV sum, so ranks are compared at 1e-6 absolute (ranks are <= 1) and
+1e-5 relative; the iteration count may differ by one when the residual grazes `tolerance`."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def upload(spmv, rp, ci, va, n):
+    A = spmv.csr_from_arrays(n, n, rp, ci, va)
+    assert spmv.csr_to_gpu(A) == 0
+    return A
+
+
+def graph(spmv, n, k, seed, dangling=()):
+    rp, ci, _ = spmv.synth.uniform_csr(seed, 0, n, n, k)
+    keep = ~np.isin(ci, np.array(list(dangling), dtype=np.int32))
+    counts = np.add.reduceat(keep.astype(np.int64), rp[:-1])
+    ci = ci[keep]
+    rp = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return rp, ci, spmv.synth.column_stochastic_values(ci, n)
+
+
+def compare(got, want):
+    assert np.max(np.abs(got - want)) < 1e-6
+    big = want > 1e-4
+    if big.any():
+        assert np.max(np.abs(got[big] - want[big]) / want[big]) < 1e-5 * 10   # a few ulps of 1/n-sized ranks
+
+
+def test_three_cycle_equal_ranks(gpu):
+    """reference tests/test_pagerank.cu:140-164"""
+    dense = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], np.float32)
+    A = gpu.csr_create(0, 0, 0)
+    gpu.csr_from_dense(A, dense, 3, 3)
+    gpu.csr_to_gpu(A)
+    r = gpu.pagerank(A)
+    assert r.converged and np.allclose(r.ranks, 1 / 3, atol=1e-4)
+    top = gpu.pagerank_top_k(r, 3, 2)                       # tests/test_pagerank.cu:166-189
+    assert len(top) == 2 and top[0][1] >= top[1][1]
+    gpu.csr_destroy(A)
+
+
+def test_score_invariants_and_oracle_parity_small_graphs(gpu, oracle):
+    """reference tests/test_pagerank.cu:18-77 (P15) + parity with the oracle at test sizes"""
+    rng = np.random.default_rng(42)
+    with_dangling = 0
+    for _ in range(25):
+        n = int(rng.integers(5, 50))
+        adj = (rng.random((n, n)) < 0.2).astype(np.float32)
+        col = adj.sum(axis=0)
+        with_dangling += int((col == 0).any())
+        adj = np.where(col > 0, adj / np.maximum(col, 1), 0).astype(np.float32)
+        if not adj.any():
+            continue
+        A = gpu.csr_create(0, 0, 0)
+        gpu.csr_from_dense(A, adj, n, n)
+        gpu.csr_to_gpu(A)
+        r = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
+        rp, ci, va = gpu.csr_host_arrays(A)
+        want, iters, res, conv = oracle.pagerank(rp, ci, va, num_cols=n)
+        assert (r.ranks >= 0).all() and abs(float(r.ranks.sum()) - 1.0) < 1e-4
+        assert (not r.converged) or r.final_residual < 1e-6
+        assert r.converged == conv and abs(r.iterations - iters) <= 1
+        compare(r.ranks, want)
+        gpu.csr_destroy(A)
+    assert with_dangling >= 3
+
+
+def test_medium_graph_with_dangling_nodes(gpu, oracle):
+    n = 200_000
+    rp, ci, va = graph(gpu, n, 12, 9, dangling=(5, 1000, 150_000))
+    A = upload(gpu, rp, ci, va, n)
+    r = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
+    want, iters, res, conv = oracle.pagerank(rp, ci, va, num_cols=n, wide_sums=True)
+    assert r.converged == conv and abs(r.iterations - iters) <= 1
+    compare(r.ranks, want)
+    top = gpu.pagerank_top_k(r, n, 10)                      # tests/test_pagerank.cu:81-137 (P16)
+    assert all(top[i][1] >= top[i + 1][1] for i in range(9))
+    assert top[0][1] == r.ranks.max()
+    gpu.csr_destroy(A)
+
+
+def test_max_iterations_and_tolerance_are_honoured(gpu, oracle):
+    n = 5000
+    rp, ci, va = graph(gpu, n, 8, 2)
+    A = upload(gpu, rp, ci, va, n)
+    r = gpu.pagerank(A, gpu.PageRankConfig(0.85, 0.0, 7))  # tol 0: never converges
+    assert r.iterations == 7 and not r.converged
+    want, *_ = oracle.pagerank(rp, ci, va, num_cols=n, tolerance=0.0, max_iterations=7, wide_sums=True)
+    compare(r.ranks, want)
+    r0 = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 0))
+    assert r0.iterations == 0 and np.allclose(r0.ranks, 1.0 / n)
+    gpu.csr_destroy(A)
+
+
+def test_null_matrix_and_not_uploaded(gpu):
+    """pagerank(nullptr) returns a default result (reference src/pagerank.cu:56-58)"""
+    r = gpu.pagerank(None)
+    assert r.ranks is None and r.iterations == 0 and not r.converged
+
+
+def test_device_only_matrix_uses_device_dangling_scan(gpu, oracle):
+    """Matrix generated straight into HBM (no host arrays): dangling columns come from the
+    device column-sum kernel and must agree with the oracle's host scan."""
+    wl = importlib.import_module("gpu-spmv_amd.workloads")
+    n = 100_000
+    A = wl.uniform_csr_device(42, n, n, 4)                  # k=4: e^-4 of the columns are empty
+    wl.make_column_stochastic(A)
+    rp, ci, va = A.to_host()
+    assert oracle.dangling_mask(rp, ci, va, n).sum() > 100
+    r = gpu.pagerank(A.handle, gpu.PageRankConfig(0.85, 1e-6, 100))
+    want, iters, res, conv = oracle.pagerank(rp, ci, va, num_cols=n, wide_sums=True)
+    assert r.converged == conv and abs(r.iterations - iters) <= 1
+    compare(r.ranks, want)
+    A.close()
+
+
+def test_shard_engine_single_rank_equals_pagerank(gpu):
+    """The multi-GPU host loop with world = 1 (HipEngine on torch tensors) must reproduce
+    spmv_c_pagerank — same kernels, two hosts."""
+    torch = pytest.importorskip("torch")
+    prd = importlib.import_module("gpu-spmv_amd.pagerank_dist")
+    n = 50_000
+    rp, ci, va = graph(gpu, n, 10, 4, dangling=(7, 9))
+    A = upload(gpu, rp, ci, va, n)
+    direct = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
+    dev = torch.device("cuda:0")
+    eng = prd.HipEngine(torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev), 0, n)
+    pr = prd.ShardedPageRank(eng, n).prepare()
+    ranks, iters, res, conv = pr.run(0.85, 1e-6, 100, check_every=3)
+    assert pr.num_dangling == 2 and conv == direct.converged and iters == direct.iterations
+    np.testing.assert_allclose(ranks, direct.ranks, rtol=0, atol=1e-9)
+    eng.close()
+    gpu.csr_destroy(A)
+
+
+def test_two_shards_on_one_gpu_equal_one_shard(gpu, oracle):
+    """Row-shard simulator on one device: two engines stepping halves of the matrix, the
+    host playing the collective (sum of partials, slices written in place), must match the
+    unsharded run bit for bit in the ranks each shard writes."""
+    torch = pytest.importorskip("torch")
+    prd = importlib.import_module("gpu-spmv_amd.pagerank_dist")
+    n = 40_000
+    rp, ci, va = graph(gpu, n, 10, 8, dangling=(11,))
+    dev = torch.device("cuda:0")
+
+    def engine(b, e):
+        lrp = torch.from_numpy((rp[b:e + 1] - rp[b]).astype(np.int32)).to(dev)
+        return prd.HipEngine(lrp, torch.from_numpy(ci[rp[b]:rp[e]]).to(dev), torch.from_numpy(va[rp[b]:rp[e]]).to(dev), b, n)
+
+    whole, lo, hi = engine(0, n), engine(0, n // 2), engine(n // 2, n)
+    pr = prd.ShardedPageRank(whole, n).prepare()
+    mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+    mask[:n] = ((lo.column_sums() + hi.column_sums()) == 0).to(torch.uint8)
+    assert int(mask.sum()) == pr.num_dangling == 1
+    lo.set_dangling_mask(mask)
+    hi.set_dangling_mask(mask)
+    start = prd.initial_dangling_mass(1, n)
+    pr.reset()
+    lo.reset(start)
+    hi.reset(start)
+    r = [torch.full((n,), 1.0 / n, dtype=torch.float32, device=dev) for _ in range(2)]
+    for k in range(6):
+        pr.iterate(k, 0.85, 0.0)
+        old, new = r[k & 1], r[(k + 1) & 1]
+        s = lo.step(old, new, 0.85).clone() + hi.step(old, new, 0.85)
+        lo.commit(s, 0.0)
+        hi.commit(s, 0.0)
+        torch.testing.assert_close(new, pr.r[(k + 1) & 1][:n], rtol=0, atol=0)
+    assert lo.status()[0] == hi.status()[0] == whole.status()[0] == 6
+    assert abs(lo.status()[1] - whole.status()[1]) <= 1e-12 + 1e-6 * whole.status()[1]
+    for e in (whole, lo, hi):
+        e.close()

@@ -1,0 +1,225 @@
+"""CPU-side tests of libspmv_amd.so: the C ABI loads without a GPU and exports every
+symbol include/spmv_c.h declares; host-side containers, serialisers, statistics,
+selector and the host SpMV path reproduce the reference's outputs bit for bit
+(golden fixture made from the compiled reference).  No device compute here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, ROOT
+
+
+@pytest.fixture(scope="module")
+def golden():
+    data = np.load(os.path.join(GOLDEN_DIR, "ref_cases.npz"), allow_pickle=False)
+    return data, [str(n) for n in data["case_names"]]
+
+
+def test_library_exports_every_declared_symbol(spmv):
+    header = open(os.path.join(ROOT, "include", "spmv_c.h")).read()
+    declared = set(re.findall(r"\b(spmv_c_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 60
+    handle = ctypes.CDLL(spmv.LIB_PATH)
+    missing = [name for name in sorted(declared) if not hasattr(handle, name)]
+    assert not missing, missing
+    assert declared == set(spmv.EXPORTED_SYMBOLS)      # the Python mirror binds all of them
+
+
+def test_struct_sizes_match_reference_abi(spmv):
+    """sizeof on x86-64 SysV"""
+    assert ctypes.sizeof(spmv.CSRMatrix) == 72 and spmv.CSRMatrix.d_values.offset == 40
+    assert spmv.CSRMatrix.owns_host_memory.offset == 64
+    assert ctypes.sizeof(spmv.ELLMatrix) == 56
+    assert ctypes.sizeof(spmv.SpMVConfig) == 12 and ctypes.sizeof(spmv.SpMVResult) == 24
+    assert ctypes.sizeof(spmv.CSRStats) == 16 and ctypes.sizeof(spmv.PageRankConfig) == 12
+    assert ctypes.sizeof(spmv._PageRankResultC) == 24 and ctypes.sizeof(spmv.TopKNode) == 8
+    assert ctypes.sizeof(spmv.BandwidthMetrics) == 12
+
+
+def test_error_strings(spmv):
+    """reference tests/test_common.cpp:8-18"""
+    E = spmv.SpMVError
+    assert spmv.spmv_error_string(E.SUCCESS) == "Success"
+    assert spmv.spmv_error_string(E.INVALID_DIMENSION) == "Invalid matrix/vector dimension"
+    assert spmv.spmv_error_string(E.CUDA_MALLOC) == "CUDA memory allocation failed"
+    assert spmv.spmv_error_string(E.CUDA_MEMCPY) == "CUDA memory copy failed"
+    assert spmv.spmv_error_string(E.KERNEL_LAUNCH) == "CUDA kernel launch failed"
+    assert spmv.spmv_error_string(E.INVALID_FORMAT) == "Invalid sparse matrix format"
+    assert spmv.spmv_error_string(E.FILE_IO) == "File I/O error"
+    assert spmv.spmv_error_string(E.OUT_OF_MEMORY) == "Out of memory"
+    assert spmv.spmv_error_string(E.INVALID_ARGUMENT) == "Invalid argument"
+    assert spmv.spmv_error_string(-99) == "Unknown error"
+
+
+def test_defaults(spmv):
+    c = spmv.SpMVConfig()
+    assert (c.kernel_type, c.block_size, c.use_texture) == (spmv.SpMVConfig.SCALAR_CSR, 256, 0)
+    p = spmv.PageRankConfig()
+    assert p.damping_factor == pytest.approx(0.85) and p.tolerance == pytest.approx(1e-6) and p.max_iterations == 100
+
+
+def test_cuda_buffer_host_side_semantics(spmv):
+    """reference tests/test_common.cpp:21-98 — the parts that need no device"""
+    b = spmv.CudaBuffer()
+    assert b.get() is None and b.size() == 0 and b.empty()
+    z = spmv.CudaBuffer(0)
+    assert z.get() is None and z.empty()
+    with pytest.raises(RuntimeError, match="Copy size exceeds buffer size"):
+        z.copyFromHost(np.zeros(4, np.float32), 4)
+    with pytest.raises(RuntimeError, match="Copy size exceeds buffer size"):
+        z.copyToHost(1)
+    z.release()
+    assert z.size() == 0
+
+
+def test_csr_container_against_reference_outputs(spmv, golden, tmp_path):
+    data, names = golden
+    for n in names:
+        dense = data[f"{n}/dense"]
+        rows, cols = dense.shape
+        A = spmv.csr_create(0, 0, 0)
+        assert spmv.csr_from_dense(A, dense, rows, cols) == int(data[f"{n}/csr_from_dense_status"][0])
+        rp, ci, va = spmv.csr_host_arrays(A)
+        np.testing.assert_array_equal(rp, data[f"{n}/csr_row_ptrs"], err_msg=n)       # bit-exact indexing
+        np.testing.assert_array_equal(ci, data[f"{n}/csr_col_indices"], err_msg=n)
+        np.testing.assert_array_equal(va.view(np.uint32), data[f"{n}/csr_values"].view(np.uint32), err_msg=n)
+        m = A.contents
+        assert [m.num_rows, m.num_cols, m.nnz] == list(data[f"{n}/csr_shape"])
+
+        np.testing.assert_array_equal(spmv.csr_to_dense(A).reshape(-1), data[f"{n}/csr_to_dense"])
+        diag = [spmv.csr_get_element(A, i, i) for i in range(min(rows, cols))]
+        np.testing.assert_array_equal(np.array(diag, np.float32), data[f"{n}/csr_get_diag"])
+
+        st = spmv.csr_compute_stats(A)
+        ref = data[f"{n}/csr_stats"]
+        assert (np.float32(st.avg_nnz_per_row), st.max_nnz_per_row, st.min_nnz_per_row, np.float32(st.skewness)) == \
+               (ref[0], int(ref[1]), int(ref[2]), ref[3]), n
+        cfg = spmv.spmv_auto_config(A)
+        assert [cfg.kernel_type, cfg.block_size, cfg.use_texture] == list(data[f"{n}/auto_config"]), n
+
+        # host SpMV path of the library (API parity with the reference's CPU path)
+        y = spmv.spmv_cpu_csr(A, data[f"{n}/x"])
+        np.testing.assert_array_equal(y.view(np.uint32), data[f"{n}/y_csr"].view(np.uint32), err_msg=n)
+
+        # on-disk format is byte-identical to the reference's file
+        path = tmp_path / f"{n}.csr"
+        assert spmv.csr_serialize(A, str(path)) == 0
+        assert path.read_bytes() == data[f"{n}/csr_file"].tobytes(), n
+        B = spmv.csr_create(0, 0, 0)
+        assert spmv.csr_deserialize(B, str(path)) == 0
+        for a, b in zip(spmv.csr_host_arrays(A), spmv.csr_host_arrays(B)):
+            np.testing.assert_array_equal(a, b)
+        spmv.csr_destroy(B)
+        spmv.csr_destroy(A)
+
+
+def test_ell_container_against_reference_outputs(spmv, golden, tmp_path):
+    data, names = golden
+    for n in names:
+        dense = data[f"{n}/dense"]
+        rows, cols = dense.shape
+        A = spmv.csr_create(0, 0, 0)
+        spmv.csr_from_dense(A, dense, rows, cols)
+        E = spmv.ell_create(0, 0, 0)
+        assert spmv.ell_from_csr(E, A) == 0
+        e = E.contents
+        assert [e.num_rows, e.num_cols, e.max_nnz_per_row] == list(data[f"{n}/ell_shape"]), n
+        ecols, evals = spmv.ell_host_arrays(E)
+        np.testing.assert_array_equal(ecols, data[f"{n}/ell_col_indices"], err_msg=n)
+        np.testing.assert_array_equal(evals.view(np.uint32), data[f"{n}/ell_values"].view(np.uint32), err_msg=n)
+
+        E2 = spmv.ell_create(0, 0, 0)
+        assert spmv.ell_from_dense(E2, dense, rows, cols) == 0
+        c2, v2 = spmv.ell_host_arrays(E2)
+        np.testing.assert_array_equal(c2, data[f"{n}/ell_dense_col_indices"], err_msg=n)
+        np.testing.assert_array_equal(v2.view(np.uint32), data[f"{n}/ell_dense_values"].view(np.uint32))
+
+        y = spmv.spmv_cpu_ell(E, data[f"{n}/x"])
+        np.testing.assert_array_equal(y.view(np.uint32), data[f"{n}/y_ell"].view(np.uint32), err_msg=n)
+        np.testing.assert_array_equal(spmv.ell_to_dense(E), dense)
+        # padding slots are (-1, 0.0f) and slot (row, k) sits at k*rows + row (tests/test_ell.cpp:48-108)
+        assert ((ecols >= 0) | (evals == 0)).all()
+        if e.max_nnz_per_row:
+            assert spmv.ell_index(rows - 1, e.max_nnz_per_row - 1, rows) == rows * e.max_nnz_per_row - 1
+
+        path = tmp_path / f"{n}.ell"
+        assert spmv.ell_serialize(E, str(path)) == 0
+        assert path.read_bytes() == data[f"{n}/ell_file"].tobytes(), n
+        E3 = spmv.ell_create(0, 0, 0)
+        assert spmv.ell_deserialize(E3, str(path)) == 0
+        for a, b in zip(spmv.ell_host_arrays(E), spmv.ell_host_arrays(E3)):
+            np.testing.assert_array_equal(a, b)
+        for h in (E, E2, E3):
+            spmv.ell_destroy(h)
+        spmv.csr_destroy(A)
+
+
+def test_argument_validation_matches_reference(spmv, tmp_path):
+    """create with negative sizes -> null; null/empty inputs -> INVALID_ARGUMENT; bad file -> FILE_IO;
+    out-of-range element query -> 0 (reference src/csr_matrix.cpp:10-13,51-53,117-119,237-239)."""
+    E = spmv.SpMVError
+    assert spmv.csr_create(-1, 2, 3) is None and spmv.ell_create(1, -2, 3) is None
+    A = spmv.csr_create(0, 0, 0)
+    assert spmv.csr_from_dense(A, None, 3, 3) == E.INVALID_ARGUMENT
+    assert spmv.csr_from_dense(A, np.ones((2, 2), np.float32), 0, 2) == E.INVALID_ARGUMENT
+    assert spmv.csr_deserialize(A, str(tmp_path / "missing.bin")) == E.FILE_IO
+    (tmp_path / "short.bin").write_bytes(b"\x01\x00\x00\x00")
+    assert spmv.csr_deserialize(A, str(tmp_path / "short.bin")) == E.FILE_IO
+    assert spmv.csr_serialize(A, str(tmp_path / "no_such_dir" / "x.bin")) == E.FILE_IO
+    spmv.csr_from_dense(A, np.eye(3, dtype=np.float32), 3, 3)
+    assert spmv.csr_get_element(A, 5, 0) == 0.0 and spmv.csr_get_element(A, 0, -1) == 0.0
+    assert spmv.csr_get_element(A, 1, 1) == 1.0
+    assert spmv.csr_from_gpu(A) == E.INVALID_ARGUMENT          # nothing on the device
+    spmv.csr_destroy(A)
+    assert spmv.spmv_validate_dimensions(5, 5) and not spmv.spmv_validate_dimensions(5, 6)
+
+
+def test_selector_properties(spmv, oracle):
+    """reference tests/test_kernel_selector.cpp:17-137 (P11 + threshold units)."""
+    rng = np.random.default_rng(42)
+    for _ in range(60):
+        rows, cols = int(rng.integers(10, 200)), int(rng.integers(10, 200))
+        dense = np.where(rng.random((rows, cols)) < rng.uniform(0.01, 0.5), 1.0, 0.0).astype(np.float32)
+        A = spmv.csr_create(0, 0, 0)
+        spmv.csr_from_dense(A, dense, rows, cols)
+        cfg = spmv.spmv_auto_config(A)
+        assert 32 <= cfg.block_size <= 1024 and cfg.block_size % 32 == 0
+        assert cfg.kernel_type in (0, 1, 2)
+        st = spmv.csr_compute_stats(A)
+        if st.avg_nnz_per_row < 4.0:
+            assert cfg.kernel_type == spmv.SpMVConfig.SCALAR_CSR
+        elif st.skewness < 10.0:
+            assert cfg.kernel_type == spmv.SpMVConfig.VECTOR_CSR
+        spmv.csr_destroy(A)
+    dense = np.zeros((100, 1000), np.float32)
+    dense[:, ::100] = 1.0
+    A = spmv.csr_create(0, 0, 0)
+    spmv.csr_from_dense(A, np.zeros((10, 10001), np.float32) + np.eye(10, 10001, dtype=np.float32), 10, 10001)
+    assert spmv.spmv_auto_config(A).use_texture == 1           # cols > 10000
+    spmv.csr_destroy(A)
+
+
+def test_bandwidth_model_host_side(spmv, oracle):
+    """reference tests/test_bandwidth.cu:100-113: zero elapsed => zero metrics; byte model = oracle's."""
+    A = spmv.csr_create(0, 0, 0)
+    spmv.csr_from_dense(A, np.eye(8, dtype=np.float32), 8, 8)
+    z = spmv.compute_bandwidth_csr(A, 0.0)
+    assert (z.achieved_bandwidth_gb_s, z.theoretical_bandwidth_gb_s, z.efficiency) == (0.0, 0.0, 0.0)
+    m = spmv.compute_bandwidth_csr(A, 1.0)
+    assert m.achieved_bandwidth_gb_s == pytest.approx(oracle.bytes_csr(8, 8, 8) / 1e9 / 1e-3, rel=1e-6)
+    assert 0 < m.theoretical_bandwidth_gb_s < 10000 and 0 <= m.efficiency <= 1
+    spmv.csr_destroy(A)
+
+
+def test_product_never_imports_the_oracle():
+    """The library and its Python mirror must not route through oracle/ (tier rule 3)."""
+    pkg = os.path.join(ROOT, "gpu-spmv_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "spmv_oracle" not in text and "liboracle" not in text, f

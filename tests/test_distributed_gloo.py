@@ -130,7 +130,7 @@ def test_sharded_pagerank_equals_unsharded_oracle(spmv, oracle, tmp_path, world)
     assert conv
     for o in outs:                                          # every rank holds the same full answer
         np.testing.assert_array_equal(o["ranks"], outs[0]["ranks"])
-        assert int(o["num_dangling"]) == len(dangling)
+        assert int(o["num_dangling"]) == int(oracle.dangling_mask(rp, ci, va, n).sum()) >= len(dangling)
         assert bool(o["conv"]) and abs(int(o["iters"]) - iters) <= 1
         assert np.max(np.abs(o["ranks"] - want)) < 1e-6
         assert abs(float(o["ranks"].sum()) - 1.0) < 1e-4 and (o["ranks"] >= 0).all()

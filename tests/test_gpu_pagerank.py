@@ -121,7 +121,7 @@ def test_device_only_matrix_uses_device_dangling_scan(gpu, oracle):
     A.close()
 
 
-def test_shard_engine_single_rank_equals_pagerank(gpu):
+def test_shard_engine_single_rank_equals_pagerank(gpu, oracle):
     """The multi-GPU host loop with world = 1 (HipEngine on torch tensors) must reproduce
     spmv_c_pagerank — same kernels, two hosts."""
     torch = pytest.importorskip("torch")
@@ -134,7 +134,8 @@ def test_shard_engine_single_rank_equals_pagerank(gpu):
     eng = prd.HipEngine(torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev), 0, n)
     pr = prd.ShardedPageRank(eng, n).prepare()
     ranks, iters, res, conv = pr.run(0.85, 1e-6, 100, check_every=3)
-    assert pr.num_dangling == 2 and conv == direct.converged and iters == direct.iterations
+    assert pr.num_dangling == int(oracle.dangling_mask(rp, ci, va, n).sum()) >= 2
+    assert conv == direct.converged and iters == direct.iterations
     np.testing.assert_allclose(ranks, direct.ranks, rtol=0, atol=1e-9)
     eng.close()
     gpu.csr_destroy(A)
@@ -158,10 +159,11 @@ def test_two_shards_on_one_gpu_equal_one_shard(gpu, oracle):
     pr = prd.ShardedPageRank(whole, n).prepare()
     mask = torch.zeros(n, dtype=torch.uint8, device=dev)
     mask[:n] = ((lo.column_sums() + hi.column_sums()) == 0).to(torch.uint8)
-    assert int(mask.sum()) == pr.num_dangling == 1
+    num_dangling = int(oracle.dangling_mask(rp, ci, va, n).sum())
+    assert int(mask.sum()) == pr.num_dangling == num_dangling >= 1
     lo.set_dangling_mask(mask)
     hi.set_dangling_mask(mask)
-    start = prd.initial_dangling_mass(1, n)
+    start = prd.initial_dangling_mass(num_dangling, n)
     pr.reset()
     lo.reset(start)
     hi.reset(start)

@@ -144,7 +144,8 @@ def test_shard_engine_single_rank_equals_pagerank(gpu, oracle):
 def test_two_shards_on_one_gpu_equal_one_shard(gpu, oracle):
     """Row-shard simulator on one device: two engines stepping halves of the matrix, the
     host playing the collective (sum of partials, slices written in place), must match the
-    unsharded run bit for bit in the ranks each shard writes."""
+    unsharded run.  Not bit for bit: a shard's rebased row_ptrs change which 16-byte group an
+    entry falls in, hence the order of a row's fp32 sum (last-ulp differences)."""
     torch = pytest.importorskip("torch")
     prd = importlib.import_module("gpu-spmv_amd.pagerank_dist")
     n = 40_000
@@ -174,7 +175,7 @@ def test_two_shards_on_one_gpu_equal_one_shard(gpu, oracle):
         s = lo.step(old, new, 0.85).clone() + hi.step(old, new, 0.85)
         lo.commit(s, 0.0)
         hi.commit(s, 0.0)
-        torch.testing.assert_close(new, pr.r[(k + 1) & 1][:n], rtol=0, atol=0)
+        torch.testing.assert_close(new, pr.r[(k + 1) & 1][:n], rtol=2e-6, atol=0)
     assert lo.status()[0] == hi.status()[0] == whole.status()[0] == 6
     assert abs(lo.status()[1] - whole.status()[1]) <= 1e-12 + 1e-6 * whole.status()[1]
     for e in (whole, lo, hi):

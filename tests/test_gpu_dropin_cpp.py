@@ -1,0 +1,18 @@
+"""Runs tests/cpp/dropin_smoke (a C++ caller written like the reference's gtest files,
+compiled with plain g++ by __graft_entry__.build()) on the GPU: the C++ boundary
+(namespace spmv, CudaBuffer, struct fields) is a source-level drop-in."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cpp_dropin_caller(gpu):
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "dropin_smoke")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout + out.stderr

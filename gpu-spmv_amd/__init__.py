@@ -176,6 +176,7 @@ _SIGNATURES = {
                                 POINTER(SpMVResult)]),
     "spmv_c_auto_config": (c_int, [POINTER(CSRMatrix), POINTER(SpMVConfig)]),
     "spmv_c_validate_dimensions": (c_int, [c_int, c_int]),
+    "spmv_c_csr_has_tiled_plan": (c_int, [POINTER(CSRMatrix)]),
     "spmv_c_spmv_csr_async": (c_int, [POINTER(CSRMatrix), c_void_p, c_void_p, POINTER(SpMVConfig), c_int,
                                       c_void_p]),
     "spmv_c_spmv_ell_async": (c_int, [POINTER(ELLMatrix), c_void_p, c_void_p, POINTER(SpMVConfig), c_int,
@@ -545,6 +546,10 @@ def spmv_ell(A, d_x, d_y, config=None, vec_size=-1) -> SpMVResult:
     lib().spmv_c_spmv_ell(A, _dev(d_x), _dev(d_y), byref(config) if config is not None else None,
                           vec_size, byref(out))
     return out
+
+
+def csr_has_tiled_plan(A) -> bool:
+    return bool(lib().spmv_c_csr_has_tiled_plan(A))
 
 
 def spmv_csr_async(A, d_x, d_y, config=None, vec_size=-1, stream=None) -> int:

@@ -4,6 +4,7 @@
 // precompute (row statistics, merge-path tile table, ELL slot count) is keyed
 // by the matrix's device index array and dropped in csr_free_gpu / ell_free_gpu.
 #include "internal.h"
+#include "tiled.h"
 
 #include <mutex>
 #include <unordered_map>
@@ -27,6 +28,7 @@ void release(CsrAux* a) {
     if (a->d_tile_rows) (void)hipFree(a->d_tile_rows);
     if (a->d_carry_row) (void)hipFree(a->d_carry_row);
     if (a->d_carry_val) (void)hipFree(a->d_carry_val);
+    if (a->tiled) tiled_free(a->tiled);
     delete a;
 }
 
@@ -56,6 +58,25 @@ void aux_drop(const void* key) {
         t.erase(it);
     }
     release(victim);
+}
+
+const TiledPlan* tiled_plan_for(const CSRMatrix* A, hipStream_t s) {
+    if (!A || !A->d_row_ptrs || !tiled_eligible(A)) return nullptr;
+    CsrAux* aux = aux_lookup(A->d_row_ptrs, true);
+    if (aux->tiled && (aux->tiled->num_rows != A->num_rows || aux->tiled->num_cols != A->num_cols ||
+                       aux->tiled->nnz != A->nnz)) {
+        tiled_free(aux->tiled);       // header changed under the same device arrays
+        aux->tiled = nullptr;
+        aux->tiled_failed = false;
+    }
+    if (!aux->tiled && !aux->tiled_failed) {
+        if (tiled_build(A, &aux->tiled, s) != hipSuccess) {
+            (void)hipGetLastError();
+            aux->tiled = nullptr;
+            aux->tiled_failed = true;
+        }
+    }
+    return aux->tiled;
 }
 
 EllAux* ell_aux_lookup(const void* key, bool create) {

@@ -3,6 +3,7 @@
 #include "internal.h"
 #include "generators.h"
 #include "pagerank_engine.h"
+#include "tiled.h"
 #include "spmv/bandwidth.h"
 #include "spmv/pagerank.h"
 #include "spmv_c.h"
@@ -229,6 +230,13 @@ int spmv_c_validate_dimensions(int num_cols, int vec_size) {
     return spmv_validate_dimensions(num_cols, vec_size) ? 1 : 0;
 }
 
+int spmv_c_csr_has_tiled_plan(const spmv_c_csr* A_c) {
+    const CSRMatrix* A = cxx(A_c);
+    if (!A || !A->d_row_ptrs) return 0;
+    detail::CsrAux* aux = detail::aux_lookup(A->d_row_ptrs, false);
+    return aux && aux->tiled ? 1 : 0;
+}
+
 int spmv_c_spmv_csr_async(const spmv_c_csr* A, const float* d_x, float* d_y,
                           const spmv_c_config* config, int vec_size, void* hip_stream) {
     return spmv_csr_async(cxx(A), d_x, d_y, cxx(config), vec_size, as_stream(hip_stream));
@@ -298,13 +306,13 @@ spmv_c_pr_shard* spmv_c_pr_shard_create(const spmv_c_csr* A_local, int row_offse
     sh.d_cols = A->d_col_indices;
     sh.d_vals = A->d_values;
     sh.d_dangling = d_dangling_mask;
+    const int partial_pairs = detail::pr_shard_prepare(&sh, detail::tiled_plan_for(A, nullptr));
     if (hipMalloc(reinterpret_cast<void**>(&sh.d_state), sizeof(detail::PrState)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&sh.d_block_partials),
-                  2 * sizeof(double) * detail::pr_max_blocks()) != hipSuccess) {
+                  2 * sizeof(double) * static_cast<size_t>(partial_pairs)) != hipSuccess) {
         spmv_c_pr_shard_destroy(h);
         return nullptr;
     }
-    detail::pr_shard_prepare(&sh);
     return h;
 }
 

@@ -87,6 +87,31 @@ __device__ __forceinline__ float row_partial_dot(int begin, int end, int lane, l
     return acc;
 }
 
+// block-wide sum of two doubles; result valid in thread 0
+__device__ __forceinline__ void block_sum2(double& a, double& b) {
+    __shared__ double s_a[kBlock / 64];
+    __shared__ double s_b[kBlock / 64];
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_a[wave] = a;
+        s_b[wave] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = s_a[0];
+        b = s_b[0];
+        for (int w = 1; w < kBlock / 64; ++w) {
+            a += s_a[w];
+            b += s_b[w];
+        }
+    }
+    __syncthreads();
+}
+
 } // namespace dev
 } // namespace detail
 } // namespace spmv

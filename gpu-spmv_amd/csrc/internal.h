@@ -18,6 +18,8 @@ inline int code(SpMVError e) { return static_cast<int>(e); }
 // ---- per-matrix auxiliary data (side table keyed by the device row_ptrs) ----
 // The public structs cannot grow (callers poke the fields), so anything the
 // kernels precompute for a matrix lives here and is dropped by csr_free_gpu.
+struct TiledPlan;
+
 struct CsrAux {
     // row-length statistics computed once (host scan or device reduction)
     bool   have_stats = false;
@@ -29,7 +31,13 @@ struct CsrAux {
     // merge-path carry-out slots
     int*   d_carry_row = nullptr;    // [num_tiles]
     float* d_carry_val = nullptr;    // [num_tiles]
+    // LDS-tiled engine: bucketed copy of the entries, built on first use (tiled.h)
+    TiledPlan* tiled = nullptr;
+    bool tiled_failed = false;       // build failed once (e.g. out of memory): do not retry
 };
+
+// the matrix's tiled plan (built on first call), or nullptr when not eligible / not buildable
+const TiledPlan* tiled_plan_for(const CSRMatrix* A, hipStream_t s);
 
 CsrAux* aux_lookup(const void* key, bool create);
 void    aux_drop(const void* key);

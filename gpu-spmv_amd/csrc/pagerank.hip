@@ -20,6 +20,7 @@
 #include "internal.h"
 #include "device_common.h"
 #include "pagerank_engine.h"
+#include "tiled.h"
 #include "spmv/pagerank.h"
 
 #include <hip/hip_runtime.h>
@@ -34,31 +35,6 @@ namespace detail {
 namespace {
 
 using namespace dev;
-
-// block-wide sum of two doubles; result valid in thread 0
-__device__ __forceinline__ void block_sum2(double& a, double& b) {
-    __shared__ double s_a[kBlock / 64];
-    __shared__ double s_b[kBlock / 64];
-    for (int off = 32; off > 0; off >>= 1) {
-        a += __shfl_xor(a, off, 64);
-        b += __shfl_xor(b, off, 64);
-    }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        s_a[wave] = a;
-        s_b[wave] = b;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        a = s_a[0];
-        b = s_b[0];
-        for (int w = 1; w < kBlock / 64; ++w) {
-            a += s_a[w];
-            b += s_b[w];
-        }
-    }
-    __syncthreads();
-}
 
 // One power-iteration step over this shard's rows.
 template <int LANES>
@@ -194,15 +170,21 @@ hipError_t launch_step(const PrShard& sh, const float* r_old, float* r_new, floa
 
 int pr_max_blocks() { return kMaxResidentBlocks; }
 
-void pr_shard_prepare(PrShard* sh) {
+int pr_shard_prepare(PrShard* sh, const TiledPlan* tiled) {
     const float avg = sh->local_rows > 0 ? static_cast<float>(sh->nnz) / sh->local_rows : 0.0f;
     sh->lanes = pick_lanes_per_row(avg);
-    sh->grid = grid_for(sh->local_rows, kBlock / sh->lanes);
+    sh->tiled = tiled;
+    sh->grid = tiled ? tiled->num_tiles : grid_for(sh->local_rows, kBlock / sh->lanes);
+    return std::max(sh->grid, kMaxResidentBlocks);
 }
 
 hipError_t pr_step(const PrShard& sh, const float* r_old, float* r_new, float damping,
                    hipStream_t s) {
     if (sh.local_rows <= 0) return hipSuccess;
+    if (sh.tiled) {
+        return tiled_pagerank_step(*sh.tiled, sh.row_offset, sh.n_global, r_old, r_new, sh.d_dangling,
+                                   damping, sh.d_state, sh.d_block_partials, s);
+    }
     switch (sh.lanes) {
         case 1:  return launch_step<1>(sh, r_old, r_new, damping, s);
         case 2:  return launch_step<2>(sh, r_old, r_new, damping, s);
@@ -310,7 +292,6 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     const size_t len = static_cast<size_t>(std::max(n, adj->num_cols));
     if (r_a.alloc(len) != hipSuccess || r_b.alloc(len) != hipSuccess ||
         mask.alloc(len) != hipSuccess ||
-        partials.alloc(2 * static_cast<size_t>(detail::pr_max_blocks())) != hipSuccess ||
         sums.alloc(2) != hipSuccess || state.alloc(1) != hipSuccess ||
         dangling_count.alloc(1) != hipSuccess) {
         return result;
@@ -357,8 +338,10 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     shard.d_vals = adj->d_values;
     shard.d_dangling = mask.ptr;
     shard.d_state = state.ptr;
+    // large x: run the steps through the LDS-tiled engine (plan cached with the matrix)
+    const int partial_pairs = detail::pr_shard_prepare(&shard, detail::tiled_plan_for(adj, stream));
+    ok = ok && partials.alloc(2 * static_cast<size_t>(partial_pairs)) == hipSuccess;
     shard.d_block_partials = partials.ptr;
-    detail::pr_shard_prepare(&shard);
 
     // Pinned mirrors of the device state, two deep: the host enqueues step k+1
     // before it looks at the outcome of step k.

@@ -32,11 +32,14 @@ struct PrShard {
     PrState* d_state = nullptr;
     double* d_block_partials = nullptr;          // [2 * pr_max_blocks()]
     int lanes = 4;                               // lanes per row, from the mean row length
-    int grid = 1;
+    int grid = 1;                                // workgroups that write block partials
+    const TiledPlan* tiled = nullptr;            // set => steps run through the LDS-tiled engine
 };
 
 int pr_max_blocks();
-void pr_shard_prepare(PrShard* shard);
+// chooses lanes / grid; `tiled` (may be null) switches the step to the tiled engine.
+// Returns the number of block-partial pairs the shard needs (size of d_block_partials / 2).
+int pr_shard_prepare(PrShard* shard, const TiledPlan* tiled);
 hipError_t pr_step(const PrShard& shard, const float* d_r_old, float* d_r_new, float damping,
                    hipStream_t s);
 hipError_t pr_reduce(const PrShard& shard, double* d_sums /*[2]*/, hipStream_t s);

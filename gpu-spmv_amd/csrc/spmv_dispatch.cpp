@@ -13,6 +13,7 @@
 //   * the ELL non-padding count behind `gflops` is taken once on the device
 //     and cached per matrix instead of an O(rows*K) host scan per call.
 #include "internal.h"
+#include "tiled.h"
 #include "spmv/bandwidth.h"
 
 namespace spmv {
@@ -60,6 +61,16 @@ int check_csr(const CSRMatrix* A, const float* d_x, float* d_y, int vec_size, bo
 hipError_t enqueue_csr(const CSRMatrix* A, const float* d_x, float* d_y,
                        const SpMVConfig* config, hipStream_t stream) {
     if (A->nnz == 0) return launch_fill_zero(d_y, A->num_rows, stream);
+
+    // use_texture = "keep x on chip": on gfx950 that is the LDS-tiled engine (tiled.hip).
+    // It replaces the row-parallel kernels that reorder sums anyway; SCALAR_CSR keeps its
+    // CPU-order contract and never takes this route.
+    if (config->use_texture && (config->kernel_type == SpMVConfig::VECTOR_CSR ||
+                                config->kernel_type == SpMVConfig::MERGE_PATH)) {
+        if (const TiledPlan* plan = tiled_plan_for(A, stream)) {
+            return tiled_spmv(*plan, d_x, d_y, stream);
+        }
+    }
 
     switch (config->kernel_type) {
         case SpMVConfig::VECTOR_CSR: {

@@ -1,0 +1,60 @@
+// tiled.h — the LDS-tiled SpMV engine ("x staged into LDS tiles"): a two-phase,
+// propagation-blocking execution of y = A x for matrices whose x does not fit on chip.
+// See tiled.hip for the algorithm; this is the host-side plan object.
+#ifndef SPMV_AMD_TILED_H
+#define SPMV_AMD_TILED_H
+
+#include "internal.h"
+
+#include <cstdint>
+
+namespace spmv {
+namespace detail {
+
+struct PrState;
+
+// Per-matrix bucketed copy of the entries (built once on the device, cached in the
+// side table, dropped by csr_free_gpu).
+struct TiledPlan {
+    int num_rows = 0, num_cols = 0;
+    long long nnz = 0;
+    int strip_cols = 0;     // W: x columns per LDS strip
+    int tile_rows = 0;      // R: y rows per LDS tile
+    int num_strips = 0, num_tiles = 0;
+
+    // layout A: entries grouped by column strip (phase 1 reads these contiguously)
+    float*    a_val = nullptr;     // [nnz]
+    uint16_t* a_lcol = nullptr;    // [nnz] column - strip * W
+    int*      a_dst = nullptr;     // [nnz] position of the entry's product in layout B
+    // layout B: products grouped by row tile, strips in order inside a tile
+    uint16_t* b_lrow = nullptr;    // [nnz] row - tile * R
+    float*    prod = nullptr;      // [nnz] phase-1 output / phase-2 input
+    int*      tile_begin = nullptr;   // [num_tiles + 1] start of every tile's range in layout B
+
+    // phase-1 work items: (strip, begin, end) over layout A, at most kItemEntries each
+    int* items = nullptr;          // [3 * num_items]
+    int  num_items = 0;
+};
+
+// true when the matrix is worth (and able) to run through the tiled engine
+bool tiled_eligible(const CSRMatrix* A);
+
+// builds the plan for A's device arrays (synchronises the stream once)
+hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s);
+void tiled_free(TiledPlan* plan);
+
+// y = A x
+hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipStream_t s);
+
+// PageRank step on the same plan: r_new[row_offset + i] = d * (A r_old)_i + d*s/n + (1-d)/n,
+// block partial sums of (r_new - r_old)^2 and of r_new over dangling nodes -> block_partials
+// [2 * plan.num_tiles]; no-op when state->done.
+hipError_t tiled_pagerank_step(const TiledPlan& plan, int row_offset, int n_global,
+                               const float* d_r_old, float* d_r_new,
+                               const unsigned char* d_dangling, float damping,
+                               const PrState* d_state, double* d_block_partials, hipStream_t s);
+
+} // namespace detail
+} // namespace spmv
+
+#endif

@@ -87,10 +87,10 @@ def make_column_stochastic(A: DeviceCSR, counts: CudaBuffer = None, stream=None)
     return counts
 
 
-def time_spmv_csr(A, d_x, d_y, kernel_type, warmup=5, runs=20):
+def time_spmv_csr(A, d_x, d_y, kernel_type, warmup=5, runs=20, use_texture=False):
     """Reference benchmark protocol (include/spmv/benchmark.h:39: 5 warm-up + 20 timed calls),
     per-call kernel-only event time as reported by spmv_csr.  Returns list of ms."""
-    cfg = SpMVConfig(kernel_type=kernel_type)
+    cfg = SpMVConfig(kernel_type=kernel_type, use_texture=use_texture)
     handle = A.handle if isinstance(A, DeviceCSR) else A
     cols = handle.contents.num_cols
     for _ in range(warmup):

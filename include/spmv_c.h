@@ -175,6 +175,9 @@ int spmv_c_spmv_ell(const spmv_c_ell* A, const float* d_x, float* d_y,
                     const spmv_c_config* config, int vec_size, spmv_c_result* out);
 int spmv_c_auto_config(const spmv_c_csr* A, spmv_c_config* out);          /* spmv_auto_config */
 int spmv_c_validate_dimensions(int num_cols, int vec_size);               /* 1 = match */
+/* extension: 1 when the matrix currently holds an LDS-tiled plan (built by the first
+ * use_texture call / PageRank on a large matrix), 0 otherwise */
+int spmv_c_csr_has_tiled_plan(const spmv_c_csr* A);
 /* extension: enqueue on a caller stream without timing or synchronisation */
 int spmv_c_spmv_csr_async(const spmv_c_csr* A, const float* d_x, float* d_y,
                           const spmv_c_config* config, int vec_size, void* hip_stream);

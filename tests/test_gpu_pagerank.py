@@ -180,3 +180,17 @@ def test_two_shards_on_one_gpu_equal_one_shard(gpu, oracle):
     assert abs(lo.status()[1] - whole.status()[1]) <= 1e-12 + 1e-6 * whole.status()[1]
     for e in (whole, lo, hi):
         e.close()
+
+
+def test_pagerank_through_the_tiled_engine(gpu, oracle):
+    """A graph large enough (n >= 262144, >= 1 M entries) that pagerank() runs its steps through
+    the LDS-tiled engine; same answer as the oracle."""
+    n = 300_000
+    rp, ci, va = graph(gpu, n, 8, 21, dangling=(1, 77_777, 299_999))
+    A = upload(gpu, rp, ci, va, n)
+    r = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
+    assert gpu.csr_has_tiled_plan(A)
+    want, iters, res, conv = oracle.pagerank(rp, ci, va, num_cols=n, wide_sums=True)
+    assert r.converged == conv and abs(r.iterations - iters) <= 1
+    compare(r.ranks, want)
+    gpu.csr_destroy(A)

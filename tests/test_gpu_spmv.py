@@ -232,3 +232,71 @@ def test_config2_full_size_linearity_and_oracle(gpu, oracle):
     assert np.max(np.abs(lin - y3)) <= 1e-4 * max(1.0, np.max(np.abs(lin)))
     ym, _ = run_csr(gpu, rp, ci, va, n, x1, KERNELS["merge"])
     assert reorder_err(rp, ci, va, x1, y1, ym) <= 2 * REORDER_TOL
+
+
+# ------------------------------------------------------------ LDS-tiled engine (use_texture) --
+def run_tiled(spmv, rp, ci, va, cols, x, kernel=1, x_offset=0):
+    A = spmv.csr_from_arrays(len(rp) - 1, cols, rp, ci, va)
+    try:
+        assert spmv.csr_to_gpu(A) == 0
+        d_x = spmv.CudaBuffer(cols + 8)
+        d_y = spmv.CudaBuffer(len(rp) - 1)
+        shifted = np.concatenate([np.zeros(x_offset, np.float32), x])
+        d_x.copyFromHost(shifted, shifted.size)
+        cfg = spmv.SpMVConfig(kernel_type=kernel, use_texture=True)
+        for _ in range(2):                                   # second call reuses the cached plan
+            res = spmv.spmv_csr(A, d_x.get() + 4 * x_offset, d_y, cfg, cols)
+            assert res.error_code == 0
+        assert spmv.csr_has_tiled_plan(A), "expected the tiled engine to take this matrix"
+        return d_y.copyToHost(len(rp) - 1)
+    finally:
+        spmv.csr_destroy(A)
+
+
+@pytest.mark.parametrize("rows,cols,k", [(300_000, 400_000, 8), (131_073, 1_000_003, 9), (2_500_000, 270_000, 2)])
+def test_tiled_engine_uniform(gpu, oracle, rows, cols, k):
+    """x through LDS strips (use_texture): shapes not multiples of the strip / tile sizes."""
+    rp, ci, va = gpu.synth.uniform_csr(42, 0, rows, cols, k)
+    x = gpu.synth.vector(42, 5, cols)
+    want = oracle.spmv_csr(rp, ci, va, x)
+    for kernel in (1, 2):
+        got = run_tiled(gpu, rp, ci, va, cols, x, kernel)
+        assert reorder_err(rp, ci, va, x, want, got) <= REORDER_TOL
+
+
+def test_tiled_engine_power_law_empty_rows_and_unaligned_x(gpu, oracle):
+    cols = 600_000
+    lens = gpu.synth.power_law_lengths(42, 250_000, max_len=10000, n_cols=cols)
+    lens[::5] = 0
+    lens[-3:] = 0
+    rp, ci, va = gpu.synth.stratified_csr(42, 0, lens, cols)
+    x = gpu.synth.vector(42, 6, cols)
+    want = oracle.spmv_csr(rp, ci, va, x)
+    got = run_tiled(gpu, rp, ci, va, cols, x, 2, x_offset=1)     # x pointer only 4-byte aligned
+    assert reorder_err(rp, ci, va, x, want, got) <= REORDER_TOL
+    assert (got[lens == 0] == 0).all()
+
+
+def test_tiled_engine_nonnegative_relative_error(gpu, oracle):
+    rp, ci, va = gpu.synth.uniform_csr(3, 0, 200_000, 500_000, 16)
+    va = np.abs(va) + np.float32(0.01)
+    x = np.abs(gpu.synth.vector(3, 3, 500_000)) + np.float32(0.01)
+    got = run_tiled(gpu, rp, ci, va, 500_000, x)
+    assert max_rel_err(oracle.spmv_csr(rp, ci, va, x), got) <= REORDER_TOL
+
+
+def test_use_texture_on_small_matrix_keeps_direct_kernels(gpu, oracle):
+    """Below the size where x leaves L2 the hint is ignored (no plan is built)."""
+    rp, ci, va = gpu.synth.uniform_csr(1, 0, 5000, 20000, 8)
+    x = gpu.synth.vector(1, 1, 20000)
+    A = gpu.csr_from_arrays(5000, 20000, rp, ci, va)
+    gpu.csr_to_gpu(A)
+    d_x, d_y = gpu.CudaBuffer(20000), gpu.CudaBuffer(5000)
+    d_x.copyFromHost(x, 20000)
+    res = gpu.spmv_csr(A, d_x, d_y, gpu.SpMVConfig(kernel_type=1, use_texture=True), 20000)
+    assert res.error_code == 0 and not gpu.csr_has_tiled_plan(A)
+    assert reorder_err(rp, ci, va, x, oracle.spmv_csr(rp, ci, va, x), d_y.copyToHost(5000)) <= REORDER_TOL
+    # SCALAR_CSR keeps its CPU-order contract even with the hint
+    res = gpu.spmv_csr(A, d_x, d_y, gpu.SpMVConfig(kernel_type=0, use_texture=True), 20000)
+    np.testing.assert_array_equal(d_y.copyToHost(5000), oracle.spmv_csr(rp, ci, va, x))
+    gpu.csr_destroy(A)

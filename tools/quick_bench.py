@@ -16,9 +16,10 @@ def report(name, A, kernels=(0, 1, 2)):
     y = spmv.CudaBuffer(A.rows)
     bytes_ = A.nnz * 8 + (A.rows + 1) * 4 + A.cols * 4 + A.rows * 4
     for kt in kernels:
-        t = wl.time_spmv_csr(A, x, y, kt, warmup=3, runs=10)
+        tex = kt >= 10
+        t = wl.time_spmv_csr(A, x, y, kt % 10, warmup=3, runs=10, use_texture=tex)
         avg, best = float(np.mean(t)), float(np.min(t))
-        print(f"{name:28s} kernel={kt} avg={avg*1e3:9.1f}us min={best*1e3:9.1f}us "
+        print(f"{name:28s} kernel={kt} tiled={int(spmv.csr_has_tiled_plan(A.handle))} avg={avg*1e3:9.1f}us min={best*1e3:9.1f}us "
               f"GB/s={bytes_/avg/1e6:8.1f} frac={bytes_/avg/1e6/8000:.3f} GFLOPS={2*A.nnz/avg/1e6:8.1f}",
               flush=True)
     x.release(); y.release()
@@ -31,12 +32,12 @@ def main():
     if "c1" in which:
         A = wl.uniform_csr_device(42, 1000, 1000, 8); report("c1 1k x 8", A); A.close()
     if "c2" in which:
-        A = wl.uniform_csr_device(42, 1_000_000, 1_000_000, 16); report("c2 1M x 16", A); A.close()
+        A = wl.uniform_csr_device(42, 1_000_000, 1_000_000, 16); report("c2 1M x 16", A, kernels=(0, 1, 2, 11)); A.close()
     if "c4" in which:
         A = wl.power_law_csr_device(42, 1_000_000, 1_000_000)
-        print("c4 nnz", A.nnz, flush=True); report("c4 1M power-law", A); A.close()
+        print("c4 nnz", A.nnz, flush=True); report("c4 1M power-law", A, kernels=(1, 2, 12)); A.close()
     if "c5" in which:
-        A = wl.uniform_csr_device(42, 10_000_000, 10_000_000, 16); report("c5 10M x 16", A, kernels=(1, 2)); A.close()
+        A = wl.uniform_csr_device(42, 10_000_000, 10_000_000, 16); report("c5 10M x 16", A, kernels=(1, 11)); A.close()
 
 
 if __name__ == "__main__":

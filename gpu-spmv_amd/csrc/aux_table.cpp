@@ -64,7 +64,7 @@ const TiledPlan* tiled_plan_for(const CSRMatrix* A, hipStream_t s) {
     if (!A || !A->d_row_ptrs || !tiled_eligible(A)) return nullptr;
     CsrAux* aux = aux_lookup(A->d_row_ptrs, true);
     if (aux->tiled && (aux->tiled->num_rows != A->num_rows || aux->tiled->num_cols != A->num_cols ||
-                       aux->tiled->nnz != A->nnz)) {
+                       aux->tiled->csr_nnz != A->nnz)) {
         tiled_free(aux->tiled);       // header changed under the same device arrays
         aux->tiled = nullptr;
         aux->tiled_failed = false;

@@ -88,9 +88,10 @@ __device__ __forceinline__ float row_partial_dot(int begin, int end, int lane, l
 }
 
 // block-wide sum of two doubles; result valid in thread 0
+template <int BLOCK = kBlock>
 __device__ __forceinline__ void block_sum2(double& a, double& b) {
-    __shared__ double s_a[kBlock / 64];
-    __shared__ double s_b[kBlock / 64];
+    __shared__ double s_a[BLOCK / 64];
+    __shared__ double s_b[BLOCK / 64];
     for (int off = 32; off > 0; off >>= 1) {
         a += __shfl_xor(a, off, 64);
         b += __shfl_xor(b, off, 64);
@@ -104,7 +105,7 @@ __device__ __forceinline__ void block_sum2(double& a, double& b) {
     if (threadIdx.x == 0) {
         a = s_a[0];
         b = s_b[0];
-        for (int w = 1; w < kBlock / 64; ++w) {
+        for (int w = 1; w < BLOCK / 64; ++w) {
             a += s_a[w];
             b += s_b[w];
         }

@@ -17,23 +17,33 @@ struct PrState;
 // side table, dropped by csr_free_gpu).
 struct TiledPlan {
     int num_rows = 0, num_cols = 0;
-    long long nnz = 0;
-    int strip_cols = 0;     // W: x columns per LDS strip
-    int tile_rows = 0;      // R: y rows per LDS tile
+    long long nnz = 0;              // entries held in cells (short rows only)
+    int strip_cols = 0;             // W: x columns per LDS strip
+    int tile_rows = 0;              // R: y rows per LDS tile
     int num_strips = 0, num_tiles = 0;
+    int reduce_block = 512;         // phase-2 workgroup size (512 or 1024)
 
-    // layout A: entries grouped by column strip (phase 1 reads these contiguously)
-    float*    a_val = nullptr;     // [nnz]
-    uint16_t* a_lcol = nullptr;    // [nnz] column - strip * W
-    int*      a_dst = nullptr;     // [nnz] position of the entry's product in layout B
-    // layout B: products grouped by row tile, strips in order inside a tile
-    uint16_t* b_lrow = nullptr;    // [nnz] row - tile * R
-    float*    prod = nullptr;      // [nnz] phase-1 output / phase-2 input
-    int*      tile_begin = nullptr;   // [num_tiles + 1] start of every tile's range in layout B
+    // entries sorted by cell (strip-major, tile inside a strip)
+    float*    a_val = nullptr;      // [nnz]
+    uint16_t* a_lcol = nullptr;     // [nnz] column - strip * W
+    uint16_t* a_lrow = nullptr;     // [nnz] row - tile * R
+    float*    prod = nullptr;       // [nnz] phase-1 output / phase-2 input, same order
+    int*      cells_t = nullptr;    // [2 * num_tiles * num_strips]: (begin, length) pairs, tile-major
 
-    // phase-1 work items: (strip, begin, end) over layout A, at most kItemEntries each
-    int* items = nullptr;          // [3 * num_items]
+    // phase-1 work items: (strip, begin, end), at most kItemEntries entries each
+    int* items = nullptr;           // [3 * num_items]
     int  num_items = 0;
+
+    // rows longer than kLongRow: summed by one wavefront each from the CSR arrays
+    int*   long_rows = nullptr;     // [num_long]
+    int    num_long = 0;
+    int*   long_chunks = nullptr;   // [3 * num_long_chunks] (row, begin, end) over the CSR arrays
+    int    num_long_chunks = 0;
+    float* seed = nullptr;          // [num_rows] zeros except the long rows' sums (null if none)
+    const int*   csr_row_ptrs = nullptr;   // borrowed from the matrix
+    const int*   csr_cols = nullptr;
+    const float* csr_vals = nullptr;
+    long long    csr_nnz = 0;
 };
 
 // true when the matrix is worth (and able) to run through the tiled engine

@@ -10,21 +10,26 @@
 // enough to amortise loading its strip.  The engine therefore runs y = A x in two
 // streaming phases over a bucketed copy of the entries (propagation blocking):
 //
-//   phase 1 "expand" : entries grouped by COLUMN STRIP (W = 8192 columns = 32 KiB of
-//        LDS).  A workgroup loads its x strip into LDS once, streams (value, local
-//        column, destination) with coalesced loads, gathers x from LDS and stores the
-//        product to the entry's slot in layout B.
-//   phase 2 "reduce" : products grouped by ROW TILE (R = 2048 rows = 8 KiB of LDS),
-//        strips in order inside a tile, so phase 1's stores land in contiguous runs.
-//        A workgroup zeroes its y tile in LDS, streams (product, local row), adds into
-//        the tile and writes the tile out with coalesced stores.  gfx950's ds_add_f32
-//        is ~30x slower than its integer LDS atomics (0.38 vs 11.7 lanes/clk/CU
-//        measured), so the add is a compare-and-swap on the word's integer image
-//        (3.5 lanes/clk/CU measured, race-free for any row multiplicity).
+//   layout : entries sorted by cell = (column strip, row tile), strip-major; per entry
+//        value f32, local column u16, local row u16 (8 B, as CSR's 8 B) + a product slot.
+//   phase 1 "expand" : a workgroup loads one x strip (W = 16384 columns = 64 KiB) into
+//        LDS, streams its share of the strip's entries (value, local column) with
+//        16-byte loads, gathers x from LDS and stores the products — same order, so
+//        loads and stores are all contiguous.
+//   phase 2 "reduce" : a workgroup owns one row tile (R = 8192 rows = 32 KiB of LDS).
+//        The tile's entries are one contiguous run per strip (cell table); the waves
+//        walk the runs, add each product into the LDS tile and finally write the tile
+//        out with coalesced stores (optionally through the fused PageRank update).
+//        gfx950's ds_add_f32 is ~30x slower than its integer LDS atomics (0.38 vs 11.7
+//        lanes/clk/CU measured), so the add is a compare-and-swap on the word's integer
+//        image (3.5 lanes/clk/CU measured; race-free for any row multiplicity).
+//   long rows (more than kLongRow entries) would make thousands of lanes fight over one
+//        LDS word; they are left out of the cells and summed by one wavefront each
+//        (direct gather) into a side vector that seeds the tiles.
 //
-// HBM traffic per entry: 10 B read + 4 B written in phase 1, 6 B read in phase 2
-// (20 B vs CSR's 8 B) — but every access is a coalesced stream, which beats one
-// 64-byte random fetch per entry by ~4x at 10 M columns.
+// HBM traffic per entry: 6 B read + 4 B written in phase 1, 6 B read in phase 2
+// (16 B vs CSR's 8 B) — but all of it is streamed, which beats one 64-byte random
+// fetch per entry by a wide margin once x leaves L2.
 // The order in which a row's products are added depends on scheduling, so the low
 // bits of y may differ from run to run (as with any atomic accumulation; the
 // reference's merge-path kernel has the same property).
@@ -45,45 +50,54 @@ namespace {
 
 using namespace dev;
 
-constexpr int kStripCols = 8192;     // W
-constexpr int kTileRows = 2048;      // R
-constexpr int kItemEntries = 16384;  // phase-1 work item size
+// W (x columns per LDS strip) and R (y rows per LDS tile) are chosen per matrix
+// (choose_shape below) from these instantiations:
+//   W in {4096, 8192, 16384}  = 16 / 32 / 64 KiB of LDS in phase 1
+//   R in {1024, 2048, 4096, 8192} = 4 .. 32 KiB of LDS in phase 2
+constexpr int kMaxItemEntries = 65536;   // phase-1 work item size bounds (entries)
+constexpr int kMinItemEntries = 4096;
+constexpr int kExpandBlock = 512;     // phase-1 workgroup (8 wavefronts)
+constexpr int kLongRow = 1024;        // rows longer than this bypass the cells
+constexpr int kLongChunk = 512;       // entries per wavefront in long_rows_kernel
 constexpr long long kMaxCells = 1LL << 26;
 
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ plan building ----
-// LANES lanes walk one row; every entry is assigned to cell (strip, tile).
-template <int LANES, bool SCATTER>
+// LANES lanes walk one row; every entry of a short row is assigned to cell (strip, tile).
+// PASS 0 counts (and lists the long rows), PASS 1 scatters.
+template <int LANES, int PASS>
 __global__ __launch_bounds__(kBlock)
-void bucket_kernel(int num_rows, int num_tiles, int num_strips,
+void bucket_kernel(int num_rows, int num_tiles, int strip_cols, int tile_rows,
                    const int* __restrict__ row_ptrs, const int* __restrict__ cols,
                    const float* __restrict__ vals,
                    int* __restrict__ cell_counter,            // [num_strips * num_tiles]
-                   const int* __restrict__ offs_a,            // strip-major exclusive scan
-                   const int* __restrict__ offs_b,            // tile-major exclusive scan
+                   const int* __restrict__ offs,              // strip-major exclusive scan
                    float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
-                   int* __restrict__ a_dst, unsigned short* __restrict__ b_lrow) {
+                   unsigned short* __restrict__ a_lrow,
+                   int* __restrict__ long_rows, int* __restrict__ num_long) {
     constexpr int kRowsPerBlock = kBlock / LANES;
     const int lane = threadIdx.x % LANES;
     const long long row = static_cast<long long>(blockIdx.x) * kRowsPerBlock + threadIdx.x / LANES;
     if (row >= num_rows) return;
-    const int tile = static_cast<int>(row / kTileRows);
-    const unsigned short lrow = static_cast<unsigned short>(row % kTileRows);
-    for (int j = row_ptrs[row] + lane, end = row_ptrs[row + 1]; j < end; j += LANES) {
+    const int begin = row_ptrs[row], end = row_ptrs[row + 1];
+    if (end - begin > kLongRow) {
+        if (PASS == 0 && lane == 0) long_rows[atomicAdd(num_long, 1)] = static_cast<int>(row);
+        return;
+    }
+    const int tile = static_cast<int>(row / tile_rows);
+    const unsigned short lrow = static_cast<unsigned short>(row % tile_rows);
+    for (int j = begin + lane; j < end; j += LANES) {
         const int c = cols[j];
-        const int strip = c / kStripCols;
+        const int strip = c / strip_cols;
         const long long cell = static_cast<long long>(strip) * num_tiles + tile;
-        if (!SCATTER) {
+        if (PASS == 0) {
             atomicAdd(&cell_counter[cell], 1);
         } else {
-            const int k = atomicAdd(&cell_counter[cell], 1);
-            const int pos_a = offs_a[cell] + k;
-            const int pos_b = offs_b[static_cast<long long>(tile) * num_strips + strip] + k;
-            a_val[pos_a] = vals[j];
-            a_lcol[pos_a] = static_cast<unsigned short>(c - strip * kStripCols);
-            a_dst[pos_a] = pos_b;
-            b_lrow[pos_b] = lrow;
+            const int at = offs[cell] + atomicAdd(&cell_counter[cell], 1);
+            a_val[at] = vals[j];
+            a_lcol[at] = static_cast<unsigned short>(c - strip * strip_cols);
+            a_lrow[at] = lrow;
         }
     }
 }
@@ -100,8 +114,7 @@ void exclusive_scan_kernel(const int* __restrict__ in, long long n, int* __restr
     for (long long i = lo; i < hi; ++i) sum += in[i];
     s_part[threadIdx.x] = sum;
     __syncthreads();
-    // Hillis-Steele over the 1024 partials
-    for (int off = 1; off < 1024; off <<= 1) {
+    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele over the partials
         const long long add = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
         __syncthreads();
         s_part[threadIdx.x] += add;
@@ -115,45 +128,41 @@ void exclusive_scan_kernel(const int* __restrict__ in, long long n, int* __restr
     if (threadIdx.x == 1023) out[n] = static_cast<int>(s_part[1023]);
 }
 
+// cells_t[tile * num_strips + strip] = (begin, length) of the cell's run;
+// strip_begin[s] = first entry of strip s (s <= num_strips)
 __global__ __launch_bounds__(kBlock)
-void transpose_counts_kernel(const int* __restrict__ cnt, int num_strips, int num_tiles,
-                             int* __restrict__ cnt_t) {
+void cell_table_kernel(const int* __restrict__ offs, int num_strips, int num_tiles,
+                       int2* __restrict__ cells_t, int* __restrict__ strip_begin) {
     const long long cells = static_cast<long long>(num_strips) * num_tiles;
-    for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < cells;
+    for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i <= cells;
          i += static_cast<long long>(gridDim.x) * kBlock) {
-        const long long tile = i / num_strips, strip = i % num_strips;
-        cnt_t[i] = cnt[strip * num_tiles + tile];
+        if (i < cells) {
+            const long long tile = i / num_strips, strip = i % num_strips;
+            const long long cell = strip * num_tiles + tile;
+            cells_t[i] = make_int2(offs[cell], offs[cell + 1] - offs[cell]);
+        }
+        if (i <= num_strips) strip_begin[i] = offs[i * num_tiles];
     }
 }
 
-// tile_begin[t] = offs_b[t * num_strips]; strip_begin[s] = offs_a[s * num_tiles]
-__global__ __launch_bounds__(kBlock)
-void boundaries_kernel(const int* __restrict__ offs_a, const int* __restrict__ offs_b,
-                       int num_strips, int num_tiles, int* __restrict__ strip_begin,
-                       int* __restrict__ tile_begin) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i <= num_strips) strip_begin[i] = offs_a[static_cast<long long>(i) * num_tiles];
-    if (i <= num_tiles) tile_begin[i] = offs_b[static_cast<long long>(i) * num_strips];
-}
-
 // ------------------------------------------------------------------------ phase 1 ----
-__global__ __launch_bounds__(kBlock)
+template <int W>
+__global__ __launch_bounds__(kExpandBlock)
 void tiled_expand_kernel(const int* __restrict__ items,
                          const float* __restrict__ a_val,
                          const unsigned short* __restrict__ a_lcol,
-                         const int* __restrict__ a_dst,
                          const float* __restrict__ x, int num_cols,
                          float* __restrict__ prod) {
-    __shared__ float xs[kStripCols];
+    __shared__ float xs[W];
     const int strip = items[3 * blockIdx.x];
     const int begin = items[3 * blockIdx.x + 1];
     const int end = items[3 * blockIdx.x + 2];
 
-    const long long base = static_cast<long long>(strip) * kStripCols;
-    const int width = static_cast<int>(min(static_cast<long long>(kStripCols), num_cols - base));
+    const long long base = static_cast<long long>(strip) * W;
+    const int width = static_cast<int>(min(static_cast<long long>(W), num_cols - base));
     const float* src = x + base;
     if ((reinterpret_cast<unsigned long long>(src) & 15) == 0) {
-        for (int i = threadIdx.x * 4; i < width; i += kBlock * 4) {
+        for (int i = threadIdx.x * 4; i < width; i += kExpandBlock * 4) {
             if (i + 3 < width) {
                 *reinterpret_cast<f32x4*>(xs + i) = *reinterpret_cast<const f32x4*>(src + i);
             } else {
@@ -161,28 +170,40 @@ void tiled_expand_kernel(const int* __restrict__ items,
             }
         }
     } else {
-        for (int i = threadIdx.x; i < width; i += kBlock) xs[i] = src[i];
+        for (int i = threadIdx.x; i < width; i += kExpandBlock) xs[i] = src[i];
     }
     __syncthreads();
 
-    // four entries per lane per step; groups aligned to 4 entries (16-byte loads)
-    for (int q = (begin & ~3) + threadIdx.x * 4; q < end; q += kBlock * 4) {
+    // four entries per lane per step, groups aligned to 4 entries (16-byte loads and stores)
+    for (int q = (begin & ~3) + threadIdx.x * 4; q < end; q += kExpandBlock * 4) {
         if (q >= begin && q + 3 < end) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(a_val + q);
             const u16x4 c = *reinterpret_cast<const u16x4*>(a_lcol + q);
-            const i32x4 d = *reinterpret_cast<const i32x4*>(a_dst + q);
-            const float p0 = v[0] * xs[c[0]], p1 = v[1] * xs[c[1]];
-            const float p2 = v[2] * xs[c[2]], p3 = v[3] * xs[c[3]];
-            prod[d[0]] = p0;
-            prod[d[1]] = p1;
-            prod[d[2]] = p2;
-            prod[d[3]] = p3;
+            f32x4 p;
+            p[0] = v[0] * xs[c[0]];
+            p[1] = v[1] * xs[c[1]];
+            p[2] = v[2] * xs[c[2]];
+            p[3] = v[3] * xs[c[3]];
+            *reinterpret_cast<f32x4*>(prod + q) = p;
         } else {
-            for (int k = max(q, begin); k < min(q + 4, end); ++k) {
-                prod[a_dst[k]] = a_val[k] * xs[a_lcol[k]];
-            }
+            for (int k = max(q, begin); k < min(q + 4, end); ++k) prod[k] = a_val[k] * xs[a_lcol[k]];
         }
     }
+}
+
+// rows too long for the cells: cut into chunks of kLongChunk entries, one wavefront per
+// chunk (direct gather), chunk sums added atomically into seed[row].  seed is zero on entry
+// (zeroed at build; phase 2 re-zeroes what it consumes).
+__global__ __launch_bounds__(kBlock)
+void long_rows_kernel(const int* __restrict__ chunks /*(row, begin, end) triples*/, int num_chunks,
+                      long long nnz, const int* __restrict__ cols, const float* __restrict__ vals,
+                      const float* __restrict__ x, float* __restrict__ seed) {
+    const int which = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (which >= num_chunks) return;
+    const int row = chunks[3 * which];
+    float acc = row_partial_dot<64>(chunks[3 * which + 1], chunks[3 * which + 2], threadIdx.x & 63, nnz, cols, vals, x);
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&seed[row], acc);
 }
 
 // ------------------------------------------------------------------------ phase 2 ----
@@ -198,60 +219,100 @@ __device__ __forceinline__ void lds_add(float* slot, float v) {
     }
 }
 
-__device__ __forceinline__ void tile_accumulate(float* tile, int begin, int end,
+// Fills the LDS tile with the sums of this tile's rows.  `seed` (may be null) holds the
+// long rows' sums and zeros elsewhere.
+template <int R, int kReduceBlock>
+__device__ __forceinline__ void tile_accumulate(float* tile, int tile_index, int num_strips, int num_rows,
+                                                const int2* __restrict__ cells_t,
                                                 const float* __restrict__ prod,
-                                                const unsigned short* __restrict__ b_lrow) {
-    for (int q = (begin & ~3) + threadIdx.x * 4; q < end; q += kBlock * 4) {
-        if (q >= begin && q + 3 < end) {
-            const f32x4 p = *reinterpret_cast<const f32x4*>(prod + q);
-            const u16x4 r = *reinterpret_cast<const u16x4*>(b_lrow + q);
-            lds_add(&tile[r[0]], p[0]);
-            lds_add(&tile[r[1]], p[1]);
-            lds_add(&tile[r[2]], p[2]);
-            lds_add(&tile[r[3]], p[3]);
-        } else {
-            for (int k = max(q, begin); k < min(q + 4, end); ++k) lds_add(&tile[b_lrow[k]], prod[k]);
+                                                const unsigned short* __restrict__ a_lrow,
+                                                float* __restrict__ seed) {
+    const long long first = static_cast<long long>(tile_index) * R;
+    for (int i = threadIdx.x; i < R; i += kReduceBlock) {
+        float v = 0.0f;
+        if (seed && first + i < num_rows) {
+            v = seed[first + i];
+            if (v != 0.0f) seed[first + i] = 0.0f;      // leave the seed vector clean for the next call
+        }
+        tile[i] = v;
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int kWaves = kReduceBlock / 64;
+    constexpr int kRunsInFlight = 4;      // runs whose first 128 entries are loaded before any add
+    const int2* mine = cells_t + static_cast<long long>(tile_index) * num_strips;
+    for (int s0 = wave * 64; s0 < num_strips; s0 += kWaves * 64) {
+        // this wavefront's next 64 runs: one coalesced load of their (begin, length)
+        const int2 meta = s0 + lane < num_strips ? mine[s0 + lane] : make_int2(0, 0);
+        const int runs = min(64, num_strips - s0);
+        for (int k0 = 0; k0 < runs; k0 += kRunsInFlight) {
+            int begin[kRunsInFlight], len[kRunsInFlight];
+            float p[kRunsInFlight * 2];
+            int r[kRunsInFlight * 2];
+#pragma unroll
+            for (int j = 0; j < kRunsInFlight; ++j) {      // all loads of the group first ...
+                const int k = min(k0 + j, 63);
+                begin[j] = __shfl(meta.x, k, 64);
+                len[j] = k0 + j < runs ? __shfl(meta.y, k, 64) : 0;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = u * 64 + lane;
+                    const bool ok = i < len[j];
+                    p[2 * j + u] = ok ? prod[begin[j] + i] : 0.0f;
+                    r[2 * j + u] = ok ? a_lrow[begin[j] + i] : -1;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kRunsInFlight * 2; ++u) {      // ... then the adds
+                if (r[u] >= 0) lds_add(&tile[r[u]], p[u]);
+            }
+#pragma unroll
+            for (int j = 0; j < kRunsInFlight; ++j) {      // tails of runs longer than 128 entries
+                for (int i = 128 + lane; i < len[j]; i += 64) {
+                    lds_add(&tile[a_lrow[begin[j] + i]], prod[begin[j] + i]);
+                }
+            }
         }
     }
+    __syncthreads();
 }
 
-__global__ __launch_bounds__(kBlock)
-void tiled_reduce_kernel(const int* __restrict__ tile_begin,
+template <int R, int kReduceBlock>
+__global__ __launch_bounds__(kReduceBlock)
+void tiled_reduce_kernel(const int2* __restrict__ cells_t, int num_strips,
                          const float* __restrict__ prod,
-                         const unsigned short* __restrict__ b_lrow,
+                         const unsigned short* __restrict__ a_lrow,
+                         float* __restrict__ seed,
                          int num_rows, float* __restrict__ y) {
-    __shared__ float tile[kTileRows];
-    for (int i = threadIdx.x; i < kTileRows; i += kBlock) tile[i] = 0.0f;
-    __syncthreads();
-    tile_accumulate(tile, tile_begin[blockIdx.x], tile_begin[blockIdx.x + 1], prod, b_lrow);
-    __syncthreads();
-    const long long first = static_cast<long long>(blockIdx.x) * kTileRows;
-    for (int i = threadIdx.x; i < kTileRows && first + i < num_rows; i += kBlock) y[first + i] = tile[i];
+    __shared__ float tile[R];
+    tile_accumulate<R, kReduceBlock>(tile, blockIdx.x, num_strips, num_rows, cells_t, prod, a_lrow, seed);
+    const long long first = static_cast<long long>(blockIdx.x) * R;
+    for (int i = threadIdx.x; i < R && first + i < num_rows; i += kReduceBlock) y[first + i] = tile[i];
 }
 
 // phase 2 with the PageRank update fused into the tile write-out (cf. pr_step_kernel)
-__global__ __launch_bounds__(kBlock)
-void tiled_pagerank_reduce_kernel(const int* __restrict__ tile_begin,
+template <int R, int kReduceBlock>
+__global__ __launch_bounds__(kReduceBlock)
+void tiled_pagerank_reduce_kernel(const int2* __restrict__ cells_t, int num_strips,
                                   const float* __restrict__ prod,
-                                  const unsigned short* __restrict__ b_lrow,
+                                  const unsigned short* __restrict__ a_lrow,
+                                  float* __restrict__ seed,
                                   int local_rows, int row_offset, int n_global,
                                   const float* __restrict__ r_old, float* __restrict__ r_new,
                                   const unsigned char* __restrict__ dangling, float damping,
                                   const PrState* __restrict__ state,
                                   double* __restrict__ block_partials) {
     if (state->done) return;
-    __shared__ float tile[kTileRows];
-    for (int i = threadIdx.x; i < kTileRows; i += kBlock) tile[i] = 0.0f;
-    __syncthreads();
-    tile_accumulate(tile, tile_begin[blockIdx.x], tile_begin[blockIdx.x + 1], prod, b_lrow);
-    __syncthreads();
+    __shared__ float tile[R];
+    tile_accumulate<R, kReduceBlock>(tile, blockIdx.x, num_strips, local_rows, cells_t, prod, a_lrow, seed);
 
     const float teleport = __fdiv_rn(1.0f - damping, static_cast<float>(n_global));
     const float dangling_term = __fdiv_rn(__fmul_rn(damping, state->dangling_sum),
                                           static_cast<float>(n_global));
     double res2 = 0.0, mass = 0.0;
-    const long long first = static_cast<long long>(blockIdx.x) * kTileRows;
-    for (int i = threadIdx.x; i < kTileRows && first + i < local_rows; i += kBlock) {
+    const long long first = static_cast<long long>(blockIdx.x) * R;
+    for (int i = threadIdx.x; i < R && first + i < local_rows; i += kReduceBlock) {
         const long long node = row_offset + first + i;
         const float fresh = __fadd_rn(__fadd_rn(__fmul_rn(damping, tile[i]), dangling_term), teleport);
         r_new[node] = fresh;
@@ -259,7 +320,7 @@ void tiled_pagerank_reduce_kernel(const int* __restrict__ tile_begin,
         res2 += static_cast<double>(__fmul_rn(diff, diff));
         if (dangling[node]) mass += static_cast<double>(fresh);
     }
-    block_sum2(res2, mass);
+    block_sum2<kReduceBlock>(res2, mass);
     if (threadIdx.x == 0) {
         block_partials[2 * blockIdx.x] = res2;
         block_partials[2 * blockIdx.x + 1] = mass;
@@ -271,29 +332,106 @@ hipError_t dev_alloc(T** p, long long count) {
     return hipMalloc(reinterpret_cast<void**>(p), static_cast<size_t>(std::max<long long>(count, 1)) * sizeof(T));
 }
 
-template <int LANES, bool SCATTER>
-hipError_t launch_bucket(const CSRMatrix* A, const TiledPlan& plan, int* counter, const int* offs_a,
-                         const int* offs_b, hipStream_t s) {
+template <int LANES, int PASS>
+hipError_t launch_bucket(const CSRMatrix* A, const TiledPlan& plan, int* counter, const int* offs,
+                         int* num_long, hipStream_t s) {
     const int rows_per_block = kBlock / LANES;
     const int grid = (A->num_rows + rows_per_block - 1) / rows_per_block;
-    bucket_kernel<LANES, SCATTER><<<grid, kBlock, 0, s>>>(
-        A->num_rows, plan.num_tiles, plan.num_strips, A->d_row_ptrs, A->d_col_indices, A->d_values,
-        counter, offs_a, offs_b, plan.a_val, plan.a_lcol, plan.a_dst, plan.b_lrow);
+    bucket_kernel<LANES, PASS><<<grid, kBlock, 0, s>>>(
+        A->num_rows, plan.num_tiles, plan.strip_cols, plan.tile_rows, A->d_row_ptrs, A->d_col_indices, A->d_values,
+        counter, offs, plan.a_val, plan.a_lcol, plan.a_lrow, plan.long_rows, num_long);
     return hipGetLastError();
 }
 
-template <bool SCATTER>
+template <int PASS>
 hipError_t launch_bucket_lanes(int lanes, const CSRMatrix* A, const TiledPlan& plan, int* counter,
-                               const int* offs_a, const int* offs_b, hipStream_t s) {
+                               const int* offs, int* num_long, hipStream_t s) {
     switch (lanes) {
-        case 1:  return launch_bucket<1, SCATTER>(A, plan, counter, offs_a, offs_b, s);
-        case 2:  return launch_bucket<2, SCATTER>(A, plan, counter, offs_a, offs_b, s);
-        case 4:  return launch_bucket<4, SCATTER>(A, plan, counter, offs_a, offs_b, s);
-        case 8:  return launch_bucket<8, SCATTER>(A, plan, counter, offs_a, offs_b, s);
-        case 16: return launch_bucket<16, SCATTER>(A, plan, counter, offs_a, offs_b, s);
-        case 32: return launch_bucket<32, SCATTER>(A, plan, counter, offs_a, offs_b, s);
-        default: return launch_bucket<64, SCATTER>(A, plan, counter, offs_a, offs_b, s);
+        case 1:  return launch_bucket<1, PASS>(A, plan, counter, offs, num_long, s);
+        case 2:  return launch_bucket<2, PASS>(A, plan, counter, offs, num_long, s);
+        case 4:  return launch_bucket<4, PASS>(A, plan, counter, offs, num_long, s);
+        case 8:  return launch_bucket<8, PASS>(A, plan, counter, offs, num_long, s);
+        case 16: return launch_bucket<16, PASS>(A, plan, counter, offs, num_long, s);
+        case 32: return launch_bucket<32, PASS>(A, plan, counter, offs, num_long, s);
+        default: return launch_bucket<64, PASS>(A, plan, counter, offs, num_long, s);
     }
+}
+
+hipError_t run_long_rows(const TiledPlan& plan, const float* d_x, hipStream_t s) {
+    if (plan.num_long_chunks == 0) return hipSuccess;
+    const int per_block = kBlock / 64;
+    long_rows_kernel<<<(plan.num_long_chunks + per_block - 1) / per_block, kBlock, 0, s>>>(
+        plan.long_chunks, plan.num_long_chunks, plan.csr_nnz, plan.csr_cols, plan.csr_vals, d_x, plan.seed);
+    return hipGetLastError();
+}
+
+// W / R for a matrix: enough row tiles to fill the chip several times over, strips as
+// wide as that allows (longer runs per cell), LDS permitting.
+void choose_shape(const CSRMatrix* A, int* strip_cols, int* tile_rows) {
+    int r = 8192;
+    while (r > 1024 && (A->num_rows + r - 1) / r < 1024) r >>= 1;
+    // strips: 8192 columns (32 KiB) measured best at 10 M columns (C5: 614 us vs 622-760 us for
+    // the other shapes); narrower for matrices whose strips would otherwise be too few
+    int w = A->num_cols >= (512 << 10) ? 8192 : 4096;
+    if (const char* env = std::getenv("SPMV_TILED_STRIP")) {
+        const int v = std::atoi(env);
+        if (v == 4096 || v == 8192 || v == 16384) w = v;
+    }
+    if (const char* env = std::getenv("SPMV_TILED_TILE")) {
+        const int v = std::atoi(env);
+        if (v == 1024 || v == 2048 || v == 4096 || v == 8192) r = v;
+    }
+    *strip_cols = w;
+    *tile_rows = r;
+}
+
+hipError_t launch_expand(const TiledPlan& plan, const float* d_x, hipStream_t s) {
+    if (plan.num_items == 0) return hipSuccess;
+    switch (plan.strip_cols) {
+        case 4096:
+            tiled_expand_kernel<4096><<<plan.num_items, kExpandBlock, 0, s>>>(plan.items, plan.a_val, plan.a_lcol,
+                                                                            d_x, plan.num_cols, plan.prod);
+            break;
+        case 8192:
+            tiled_expand_kernel<8192><<<plan.num_items, kExpandBlock, 0, s>>>(plan.items, plan.a_val, plan.a_lcol,
+                                                                            d_x, plan.num_cols, plan.prod);
+            break;
+        default:
+            tiled_expand_kernel<16384><<<plan.num_items, kExpandBlock, 0, s>>>(plan.items, plan.a_val, plan.a_lcol,
+                                                                             d_x, plan.num_cols, plan.prod);
+            break;
+    }
+    return hipGetLastError();
+}
+
+template <int R>
+hipError_t launch_reduce(const TiledPlan& plan, float* d_y, hipStream_t s) {
+    const int2* cells = reinterpret_cast<const int2*>(plan.cells_t);
+    if (plan.reduce_block == 1024) {
+        tiled_reduce_kernel<R, 1024><<<plan.num_tiles, 1024, 0, s>>>(cells, plan.num_strips, plan.prod, plan.a_lrow,
+                                                                     plan.seed, plan.num_rows, d_y);
+    } else {
+        tiled_reduce_kernel<R, 512><<<plan.num_tiles, 512, 0, s>>>(cells, plan.num_strips, plan.prod, plan.a_lrow,
+                                                                   plan.seed, plan.num_rows, d_y);
+    }
+    return hipGetLastError();
+}
+
+template <int R>
+hipError_t launch_pagerank_reduce(const TiledPlan& plan, int row_offset, int n_global, const float* d_r_old,
+                                  float* d_r_new, const unsigned char* d_dangling, float damping,
+                                  const PrState* d_state, double* d_block_partials, hipStream_t s) {
+    const int2* cells = reinterpret_cast<const int2*>(plan.cells_t);
+    if (plan.reduce_block == 1024) {
+        tiled_pagerank_reduce_kernel<R, 1024><<<plan.num_tiles, 1024, 0, s>>>(
+            cells, plan.num_strips, plan.prod, plan.a_lrow, plan.seed, plan.num_rows, row_offset, n_global,
+            d_r_old, d_r_new, d_dangling, damping, d_state, d_block_partials);
+    } else {
+        tiled_pagerank_reduce_kernel<R, 512><<<plan.num_tiles, 512, 0, s>>>(
+            cells, plan.num_strips, plan.prod, plan.a_lrow, plan.seed, plan.num_rows, row_offset, n_global,
+            d_r_old, d_r_new, d_dangling, damping, d_state, d_block_partials);
+    }
+    return hipGetLastError();
 }
 
 } // namespace
@@ -308,14 +446,17 @@ bool tiled_eligible(const CSRMatrix* A) {
         return env ? std::atoll(env) : 262144LL;    // below this x sits in L2 and the direct gather wins
     }();
     if (!enabled || !A || A->num_rows <= 0 || A->nnz < (1 << 20) || A->num_cols < min_cols) return false;
-    const long long strips = (static_cast<long long>(A->num_cols) + kStripCols - 1) / kStripCols;
-    const long long tiles = (static_cast<long long>(A->num_rows) + kTileRows - 1) / kTileRows;
+    int w = 0, r = 0;
+    choose_shape(A, &w, &r);
+    const long long strips = (static_cast<long long>(A->num_cols) + w - 1) / w;
+    const long long tiles = (static_cast<long long>(A->num_rows) + r - 1) / r;
     return strips * tiles <= kMaxCells;
 }
 
 void tiled_free(TiledPlan* p) {
     if (!p) return;
-    void* owned[] = {p->a_val, p->a_lcol, p->a_dst, p->b_lrow, p->prod, p->tile_begin, p->items};
+    void* owned[] = {p->a_val, p->a_lcol, p->a_lrow, p->prod, p->cells_t, p->items, p->long_rows, p->long_chunks,
+                     p->seed};
     for (void* q : owned) if (q) (void)hipFree(q);
     delete p;
 }
@@ -325,50 +466,103 @@ hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s) {
     TiledPlan* plan = new TiledPlan();
     plan->num_rows = A->num_rows;
     plan->num_cols = A->num_cols;
-    plan->nnz = A->nnz;
-    plan->strip_cols = kStripCols;
-    plan->tile_rows = kTileRows;
-    plan->num_strips = (A->num_cols + kStripCols - 1) / kStripCols;
-    plan->num_tiles = (A->num_rows + kTileRows - 1) / kTileRows;
+    plan->csr_nnz = A->nnz;
+    plan->csr_row_ptrs = A->d_row_ptrs;
+    plan->csr_cols = A->d_col_indices;
+    plan->csr_vals = A->d_values;
+    choose_shape(A, &plan->strip_cols, &plan->tile_rows);
+    plan->reduce_block = 512;
+    if (const char* env = std::getenv("SPMV_TILED_RBLOCK")) {
+        if (std::atoi(env) == 1024) plan->reduce_block = 1024;
+    }
+    plan->num_strips = (A->num_cols + plan->strip_cols - 1) / plan->strip_cols;
+    plan->num_tiles = (A->num_rows + plan->tile_rows - 1) / plan->tile_rows;
     const long long cells = static_cast<long long>(plan->num_strips) * plan->num_tiles;
+    const long long long_capacity = A->nnz / kLongRow + 1;
 
-    int *cnt = nullptr, *cnt_t = nullptr, *offs_a = nullptr, *offs_b = nullptr, *strip_begin = nullptr;
+    int *cnt = nullptr, *offs = nullptr, *strip_begin = nullptr, *num_long = nullptr;
     auto cleanup = [&](hipError_t e) {
-        for (int* q : {cnt, cnt_t, offs_a, offs_b, strip_begin}) if (q) (void)hipFree(q);
+        for (int* q : {cnt, offs, strip_begin, num_long}) if (q) (void)hipFree(q);
         if (e != hipSuccess) tiled_free(plan);
         return e;
     };
 
     hipError_t e = dev_alloc(&cnt, cells);
-    if (e == hipSuccess) e = dev_alloc(&cnt_t, cells);
-    if (e == hipSuccess) e = dev_alloc(&offs_a, cells + 1);
-    if (e == hipSuccess) e = dev_alloc(&offs_b, cells + 1);
+    if (e == hipSuccess) e = dev_alloc(&offs, cells + 1);
     if (e == hipSuccess) e = dev_alloc(&strip_begin, plan->num_strips + 1);
-    if (e == hipSuccess) e = dev_alloc(&plan->a_val, plan->nnz);
-    if (e == hipSuccess) e = dev_alloc(&plan->a_lcol, plan->nnz + 4);
-    if (e == hipSuccess) e = dev_alloc(&plan->a_dst, plan->nnz);
-    if (e == hipSuccess) e = dev_alloc(&plan->b_lrow, plan->nnz + 4);
-    if (e == hipSuccess) e = dev_alloc(&plan->prod, plan->nnz);
-    if (e == hipSuccess) e = dev_alloc(&plan->tile_begin, plan->num_tiles + 1);
+    if (e == hipSuccess) e = dev_alloc(&num_long, 1);
+    if (e == hipSuccess) e = dev_alloc(&plan->long_rows, long_capacity);
+    if (e == hipSuccess) e = dev_alloc(&plan->cells_t, 2 * cells);
     if (e != hipSuccess) return cleanup(e);
 
     const int lanes = std::min(pick_lanes_per_row(static_cast<float>(A->nnz) / A->num_rows) * 4, 64);
-    const int small_grid = static_cast<int>(std::min<long long>((cells + kBlock - 1) / kBlock, 4096));
 
+    // pass 0: cell sizes + the list of long rows
     e = hipMemsetAsync(cnt, 0, cells * sizeof(int), s);
-    if (e == hipSuccess) e = launch_bucket_lanes<false>(lanes, A, *plan, cnt, nullptr, nullptr, s);
+    if (e == hipSuccess) e = hipMemsetAsync(num_long, 0, sizeof(int), s);
+    if (e == hipSuccess) e = launch_bucket_lanes<0>(lanes, A, *plan, cnt, nullptr, num_long, s);
     if (e == hipSuccess) {
-        exclusive_scan_kernel<<<1, 1024, 0, s>>>(cnt, cells, offs_a);
-        transpose_counts_kernel<<<small_grid, kBlock, 0, s>>>(cnt, plan->num_strips, plan->num_tiles, cnt_t);
-        exclusive_scan_kernel<<<1, 1024, 0, s>>>(cnt_t, cells, offs_b);
+        exclusive_scan_kernel<<<1, 1024, 0, s>>>(cnt, cells, offs);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, cells * sizeof(int), s);
-    if (e == hipSuccess) e = launch_bucket_lanes<true>(lanes, A, *plan, cnt, offs_a, offs_b, s);
+    int totals[2] = {0, 0};   // entries in cells, long rows
+    if (e == hipSuccess) e = hipMemcpyAsync(&totals[0], offs + cells, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&totals[1], num_long, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return cleanup(e);
+    plan->nnz = totals[0];
+    plan->num_long = totals[1];
+
+    if (plan->num_long > 0) {
+        // cut the long rows into wavefront-sized chunks (the list is short: <= nnz / kLongRow rows)
+        std::vector<int> rows(plan->num_long);
+        e = hipMemcpy(rows.data(), plan->long_rows, rows.size() * sizeof(int), hipMemcpyDeviceToHost);
+        std::vector<int> chunks;
+        std::vector<int> all_ptrs;                       // many long rows: one bulk copy instead
+        const int* host_ptrs = A->row_ptrs;
+        if (!host_ptrs && plan->num_long > 256 && e == hipSuccess) {
+            all_ptrs.resize(static_cast<size_t>(A->num_rows) + 1);
+            e = hipMemcpy(all_ptrs.data(), A->d_row_ptrs, all_ptrs.size() * sizeof(int), hipMemcpyDeviceToHost);
+            host_ptrs = all_ptrs.data();
+        }
+        for (int row : rows) {
+            int span[2] = {0, 0};
+            if (host_ptrs) {
+                span[0] = host_ptrs[row];
+                span[1] = host_ptrs[row + 1];
+            } else if (e == hipSuccess) {
+                e = hipMemcpy(span, A->d_row_ptrs + row, sizeof(span), hipMemcpyDeviceToHost);
+            }
+            for (int b = span[0]; e == hipSuccess && b < span[1]; b += kLongChunk) {
+                chunks.push_back(row);
+                chunks.push_back(b);
+                chunks.push_back(std::min(b + kLongChunk, span[1]));
+            }
+        }
+        plan->num_long_chunks = static_cast<int>(chunks.size() / 3);
+        if (e == hipSuccess) e = dev_alloc(&plan->long_chunks, static_cast<long long>(chunks.size()));
+        if (e == hipSuccess) e = hipMemcpy(plan->long_chunks, chunks.data(), chunks.size() * sizeof(int),
+                                           hipMemcpyHostToDevice);
+        if (e != hipSuccess) return cleanup(e);
+    }
+
+    e = dev_alloc(&plan->a_val, plan->nnz);
+    if (e == hipSuccess) e = dev_alloc(&plan->a_lcol, plan->nnz);
+    if (e == hipSuccess) e = dev_alloc(&plan->a_lrow, plan->nnz);
+    if (e == hipSuccess) e = dev_alloc(&plan->prod, plan->nnz);
+    if (e == hipSuccess && plan->num_long > 0) {
+        e = dev_alloc(&plan->seed, plan->num_rows);
+        if (e == hipSuccess) e = hipMemsetAsync(plan->seed, 0, static_cast<size_t>(plan->num_rows) * sizeof(float), s);
+    }
+    if (e != hipSuccess) return cleanup(e);
+
+    // pass 1: scatter the short rows' entries into their cells
+    e = hipMemsetAsync(cnt, 0, cells * sizeof(int), s);
+    if (e == hipSuccess) e = launch_bucket_lanes<1>(lanes, A, *plan, cnt, offs, num_long, s);
     if (e == hipSuccess) {
-        const int n = std::max(plan->num_strips, plan->num_tiles) + 1;
-        boundaries_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, s>>>(
-            offs_a, offs_b, plan->num_strips, plan->num_tiles, strip_begin, plan->tile_begin);
+        const int grid = static_cast<int>(std::min<long long>((cells + kBlock) / kBlock, 4096));
+        cell_table_kernel<<<grid, kBlock, 0, s>>>(offs, plan->num_strips, plan->num_tiles,
+                                                reinterpret_cast<int2*>(plan->cells_t), strip_begin);
         e = hipGetLastError();
     }
     std::vector<int> host_strip(plan->num_strips + 1);
@@ -377,13 +571,21 @@ hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s) {
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return cleanup(e);
 
-    // phase-1 work items: every strip's range cut into pieces of <= kItemEntries
+    // phase-1 work items: every strip's range cut into pieces of <= item_entries (enough
+    // pieces to fill the chip several times), piece boundaries on multiples of 4 entries
+    const int item_entries = static_cast<int>(std::min<long long>(
+        kMaxItemEntries, std::max<long long>(kMinItemEntries, (plan->nnz / 2048 + 3) / 4 * 4)));
     std::vector<int> items;
     for (int strip = 0; strip < plan->num_strips; ++strip) {
-        for (int b = host_strip[strip]; b < host_strip[strip + 1]; b += kItemEntries) {
+        int b = host_strip[strip];
+        const int stop = host_strip[strip + 1];
+        while (b < stop) {
+            int next = std::min(stop, ((b + item_entries) / 4) * 4);
+            if (next <= b) next = stop;
             items.push_back(strip);
             items.push_back(b);
-            items.push_back(std::min(b + kItemEntries, host_strip[strip + 1]));
+            items.push_back(next);
+            b = next;
         }
     }
     plan->num_items = static_cast<int>(items.size() / 3);
@@ -398,29 +600,36 @@ hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s) {
 }
 
 hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipStream_t s) {
-    if (plan.num_items > 0) {
-        tiled_expand_kernel<<<plan.num_items, kBlock, 0, s>>>(plan.items, plan.a_val, plan.a_lcol, plan.a_dst,
-                                                              d_x, plan.num_cols, plan.prod);
+    hipError_t e = run_long_rows(plan, d_x, s);
+    if (e == hipSuccess) e = launch_expand(plan, d_x, s);
+    if (e != hipSuccess) return e;
+    switch (plan.tile_rows) {
+        case 1024: return launch_reduce<1024>(plan, d_y, s);
+        case 2048: return launch_reduce<2048>(plan, d_y, s);
+        case 4096: return launch_reduce<4096>(plan, d_y, s);
+        default:   return launch_reduce<8192>(plan, d_y, s);
     }
-    tiled_reduce_kernel<<<plan.num_tiles, kBlock, 0, s>>>(plan.tile_begin, plan.prod, plan.b_lrow,
-                                                          plan.num_rows, d_y);
-    return hipGetLastError();
 }
 
 hipError_t tiled_pagerank_step(const TiledPlan& plan, int row_offset, int n_global,
                                const float* d_r_old, float* d_r_new,
                                const unsigned char* d_dangling, float damping,
                                const PrState* d_state, double* d_block_partials, hipStream_t s) {
-    // After convergence the reduce kernel returns before touching r_new; the expand kernel
-    // then only rewrites the scratch product stream, which nothing reads.
-    if (plan.num_items > 0) {
-        tiled_expand_kernel<<<plan.num_items, kBlock, 0, s>>>(plan.items, plan.a_val, plan.a_lcol, plan.a_dst,
-                                                              d_r_old, plan.num_cols, plan.prod);
+    // After convergence the reduce kernel returns before touching r_new; the other kernels
+    // then only rewrite scratch (product stream, seed vector), which nothing reads.
+    hipError_t e = run_long_rows(plan, d_r_old, s);
+    if (e == hipSuccess) e = launch_expand(plan, d_r_old, s);
+    if (e != hipSuccess) return e;
+    switch (plan.tile_rows) {
+        case 1024: return launch_pagerank_reduce<1024>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
+                                                       damping, d_state, d_block_partials, s);
+        case 2048: return launch_pagerank_reduce<2048>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
+                                                       damping, d_state, d_block_partials, s);
+        case 4096: return launch_pagerank_reduce<4096>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
+                                                       damping, d_state, d_block_partials, s);
+        default:   return launch_pagerank_reduce<8192>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
+                                                       damping, d_state, d_block_partials, s);
     }
-    tiled_pagerank_reduce_kernel<<<plan.num_tiles, kBlock, 0, s>>>(
-        plan.tile_begin, plan.prod, plan.b_lrow, plan.num_rows, row_offset, n_global, d_r_old, d_r_new,
-        d_dangling, damping, d_state, d_block_partials);
-    return hipGetLastError();
 }
 
 } // namespace detail

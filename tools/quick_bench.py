@@ -36,6 +36,8 @@ def main():
     if "c4" in which:
         A = wl.power_law_csr_device(42, 1_000_000, 1_000_000)
         print("c4 nnz", A.nnz, flush=True); report("c4 1M power-law", A, kernels=(1, 2, 12)); A.close()
+    if "c5only" in which:
+        A = wl.uniform_csr_device(42, 10_000_000, 10_000_000, 16); report("c5 10M x 16", A, kernels=(11,)); A.close()
     if "c5" in which:
         A = wl.uniform_csr_device(42, 10_000_000, 10_000_000, 16); report("c5 10M x 16", A, kernels=(1, 11)); A.close()
 

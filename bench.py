@@ -155,7 +155,10 @@ def main():
             traffic = json.load(open(pmc_file)).get("pr_step_kernel_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "pr_step_kernel (fused vector-CSR SpMV + PageRank update)",
+    tiled = spmv.csr_has_tiled_plan(engine._A)
+    step_kernels = ("tiled_expand_kernel + tiled_pagerank_reduce_kernel (LDS-tiled SpMV step, two launches)"
+                    if tiled else "pr_step_kernel (fused vector-CSR SpMV + PageRank update)")
+    roofline = {"bound": "hbm", "kernel": step_kernels,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": local_bytes}
@@ -166,7 +169,9 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (counter-based uniform random CSR generated in HBM, seed %d)" % args.seed,
         "config": {"workload": "csr_uniform_%dx%d_%d_per_row_pagerank_step" % (n, n, k), "rows": n, "cols": n,
-                   "nnz": nnz_total, "avg_nnz_per_row": k, "kernel": "VECTOR_CSR (fused PageRank step)",
+                   "nnz": nnz_total, "avg_nnz_per_row": k,
+                   "kernel": "VECTOR_CSR with x staged through LDS tiles (fused PageRank step)" if tiled
+                             else "VECTOR_CSR direct gather (fused PageRank step)",
                    "parallelism": "row-shard x%d%s" % (world, "" if world == 1 else " + RCCL all-reduce(2 f64) + all-gather(%d f32/rank)" % shard_len)},
         "gflops": round(2.0 * nnz_total * args.steps / elapsed / 1e9, 1),
         "pagerank_iters_per_sec": round(args.steps / elapsed, 2),
@@ -197,7 +202,7 @@ def api_table(spmv, wl, engine, n, k, seed):
         y = spmv.CudaBuffer(rows)
         b = csr_bytes(rows, cols, nnz)
         for kt, label in kernels:
-            t = wl.time_spmv_csr(handle, x, y, kt)
+            t = wl.time_spmv_csr(handle, x, y, kt % 10, use_texture=kt >= 10)
             avg = float(np.mean(t))
             table[f"{name}/{label}"] = {"avg_us": round(avg * 1e3, 1), "min_us": round(float(np.min(t)) * 1e3, 1),
                                         "GBps": round(b / avg / 1e6, 1), "frac": round(b / avg / 1e6 / HBM_PEAK_GBS, 4),
@@ -205,12 +210,14 @@ def api_table(spmv, wl, engine, n, k, seed):
         x.release()
         y.release()
 
-    run("c5_10Mx16", engine._A, n, n, n * k, [(1, "vector"), (2, "merge")])
+    # "+lds_tiles" = SpMVConfig::use_texture (what spmv_auto_config sets for cols > 10000)
+    run("c5_10Mx16", engine._A, n, n, n * k, [(11, "vector+lds_tiles"), (1, "vector"), (2, "merge")])
     A = wl.uniform_csr_device(seed, 1_000_000, 1_000_000, 16)
-    run("c2_1Mx16", A.handle, A.rows, A.cols, A.nnz, [(1, "vector"), (2, "merge"), (0, "scalar")])
+    run("c2_1Mx16", A.handle, A.rows, A.cols, A.nnz, [(11, "vector+lds_tiles"), (1, "vector"), (2, "merge"), (0, "scalar")])
     A.close()
     P = wl.power_law_csr_device(seed, 1_000_000, 1_000_000)
-    run("c4_1M_powerlaw_nnz%d" % P.nnz, P.handle, P.rows, P.cols, P.nnz, [(2, "merge"), (1, "vector")])
+    run("c4_1M_powerlaw_nnz%d" % P.nnz, P.handle, P.rows, P.cols, P.nnz,
+        [(12, "merge+lds_tiles"), (2, "merge"), (1, "vector")])
     P.close()
     # config 3: ELL 1M x 32 (column-major), built from a uniform CSR on the host side of the C ABI
     E = wl.uniform_ell_device(seed, 1_000_000, 1_000_000, 32)

@@ -52,11 +52,10 @@ using namespace dev;
 
 // W (x columns per LDS strip) and R (y rows per LDS tile) are chosen per matrix
 // (choose_shape below) from these instantiations:
-//   W in {4096, 8192, 16384}  = 16 / 32 / 64 KiB of LDS in phase 1
+//   W in {4096, 8192, 16384, 32768} = 16 .. 128 KiB of LDS in phase 1
 //   R in {1024, 2048, 4096, 8192} = 4 .. 32 KiB of LDS in phase 2
 constexpr int kMaxItemEntries = 65536;   // phase-1 work item size bounds (entries)
 constexpr int kMinItemEntries = 4096;
-constexpr int kExpandBlock = 512;     // phase-1 workgroup (8 wavefronts)
 constexpr int kLongRow = 1024;        // rows longer than this bypass the cells
 constexpr int kLongChunk = 512;       // entries per wavefront in long_rows_kernel
 constexpr long long kMaxCells = 1LL << 26;
@@ -146,7 +145,7 @@ void cell_table_kernel(const int* __restrict__ offs, int num_strips, int num_til
 }
 
 // ------------------------------------------------------------------------ phase 1 ----
-template <int W>
+template <int W, int kExpandBlock>
 __global__ __launch_bounds__(kExpandBlock)
 void tiled_expand_kernel(const int* __restrict__ items,
                          const float* __restrict__ a_val,
@@ -365,17 +364,25 @@ hipError_t run_long_rows(const TiledPlan& plan, const float* d_x, hipStream_t s)
     return hipGetLastError();
 }
 
-// W / R for a matrix: enough row tiles to fill the chip several times over, strips as
-// wide as that allows (longer runs per cell), LDS permitting.
+// W / R for a matrix: as many row tiles as it takes to fill the chip several times over
+// (phase 2 parallelism), strips wide enough that a cell's run averages >= ~96 entries
+// (phase 2 reads one run per cell); when even the widest strip cannot give that (wide
+// shards of a row-partitioned matrix), trade tiles for run length.
 void choose_shape(const CSRMatrix* A, int* strip_cols, int* tile_rows) {
+    auto tiles_for = [&](int r) { return (static_cast<long long>(A->num_rows) + r - 1) / r; };
+    auto strips_for = [&](int w) { return (static_cast<long long>(A->num_cols) + w - 1) / w; };
     int r = 8192;
-    while (r > 1024 && (A->num_rows + r - 1) / r < 1024) r >>= 1;
-    // strips: 8192 columns (32 KiB) measured best at 10 M columns (C5: 614 us vs 622-760 us for
-    // the other shapes); narrower for matrices whose strips would otherwise be too few
-    int w = A->num_cols >= (512 << 10) ? 8192 : 4096;
+    while (r > 1024 && tiles_for(r) < 1024) r >>= 1;
+    int w = 4096;
+    for (;;) {
+        w = 4096;
+        while (w < 32768 && A->nnz / (strips_for(w) * tiles_for(r)) < 96) w <<= 1;
+        if (A->nnz / (strips_for(w) * tiles_for(r)) >= 96 || r >= 8192) break;
+        r <<= 1;
+    }
     if (const char* env = std::getenv("SPMV_TILED_STRIP")) {
         const int v = std::atoi(env);
-        if (v == 4096 || v == 8192 || v == 16384) w = v;
+        if (v == 4096 || v == 8192 || v == 16384 || v == 32768) w = v;
     }
     if (const char* env = std::getenv("SPMV_TILED_TILE")) {
         const int v = std::atoi(env);
@@ -385,23 +392,21 @@ void choose_shape(const CSRMatrix* A, int* strip_cols, int* tile_rows) {
     *tile_rows = r;
 }
 
+template <int W, int BLOCK>
+hipError_t launch_expand_as(const TiledPlan& plan, const float* d_x, hipStream_t s) {
+    tiled_expand_kernel<W, BLOCK><<<plan.num_items, BLOCK, 0, s>>>(plan.items, plan.a_val, plan.a_lcol, d_x,
+                                                                   plan.num_cols, plan.prod);
+    return hipGetLastError();
+}
+
 hipError_t launch_expand(const TiledPlan& plan, const float* d_x, hipStream_t s) {
     if (plan.num_items == 0) return hipSuccess;
     switch (plan.strip_cols) {
-        case 4096:
-            tiled_expand_kernel<4096><<<plan.num_items, kExpandBlock, 0, s>>>(plan.items, plan.a_val, plan.a_lcol,
-                                                                            d_x, plan.num_cols, plan.prod);
-            break;
-        case 8192:
-            tiled_expand_kernel<8192><<<plan.num_items, kExpandBlock, 0, s>>>(plan.items, plan.a_val, plan.a_lcol,
-                                                                            d_x, plan.num_cols, plan.prod);
-            break;
-        default:
-            tiled_expand_kernel<16384><<<plan.num_items, kExpandBlock, 0, s>>>(plan.items, plan.a_val, plan.a_lcol,
-                                                                             d_x, plan.num_cols, plan.prod);
-            break;
+        case 4096:  return launch_expand_as<4096, 512>(plan, d_x, s);
+        case 8192:  return launch_expand_as<8192, 512>(plan, d_x, s);
+        case 16384: return launch_expand_as<16384, 512>(plan, d_x, s);
+        default:    return launch_expand_as<32768, 1024>(plan, d_x, s);   // 128 KiB of LDS: one workgroup per CU
     }
-    return hipGetLastError();
 }
 
 template <int R>
@@ -573,8 +578,9 @@ hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s) {
 
     // phase-1 work items: every strip's range cut into pieces of <= item_entries (enough
     // pieces to fill the chip several times), piece boundaries on multiples of 4 entries
+    const long long floor_entries = std::max<long long>(kMinItemEntries, plan->strip_cols);   // strip load <= 40 % of the stream
     const int item_entries = static_cast<int>(std::min<long long>(
-        kMaxItemEntries, std::max<long long>(kMinItemEntries, (plan->nnz / 2048 + 3) / 4 * 4)));
+        kMaxItemEntries, std::max<long long>(floor_entries, (plan->nnz / 2048 + 3) / 4 * 4)));
     std::vector<int> items;
     for (int strip = 0; strip < plan->num_strips; ++strip) {
         int b = host_strip[strip];

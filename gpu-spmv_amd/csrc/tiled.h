@@ -21,7 +21,7 @@ struct TiledPlan {
     int strip_cols = 0;             // W: x columns per LDS strip
     int tile_rows = 0;              // R: y rows per LDS tile
     int num_strips = 0, num_tiles = 0;
-    int reduce_block = 512;         // phase-2 workgroup size (512 or 1024)
+    int run_chunks = 2;             // 64-entry chunks read from a run per phase-2 pass (1, 2 or 4)
 
     // entries sorted by cell (strip-major, tile inside a strip)
     float*    a_val = nullptr;      // [nnz]
@@ -37,6 +37,7 @@ struct TiledPlan {
     // rows longer than kLongRow: summed by one wavefront each from the CSR arrays
     int*   long_rows = nullptr;     // [num_long]
     int    num_long = 0;
+    int    long_row = 1024;         // rows with more entries than this are "long"
     int*   long_chunks = nullptr;   // [3 * num_long_chunks] (row, begin, end) over the CSR arrays
     int    num_long_chunks = 0;
     float* seed = nullptr;          // [num_rows] zeros except the long rows' sums (null if none)

@@ -23,7 +23,7 @@
 //        gfx950's ds_add_f32 is ~30x slower than its integer LDS atomics (0.38 vs 11.7
 //        lanes/clk/CU measured), so the add is a compare-and-swap on the word's integer
 //        image (3.5 lanes/clk/CU measured; race-free for any row multiplicity).
-//   long rows (more than kLongRow entries) would make thousands of lanes fight over one
+//   long rows (more than min(1024, 2 x strips) entries) would make many lanes fight over one
 //        LDS word; they are left out of the cells and summed by one wavefront each
 //        (direct gather) into a side vector that seeds the tiles.
 //
@@ -56,7 +56,7 @@ using namespace dev;
 //   R in {1024, 2048, 4096, 8192} = 4 .. 32 KiB of LDS in phase 2
 constexpr int kMaxItemEntries = 65536;   // phase-1 work item size bounds (entries)
 constexpr int kMinItemEntries = 4096;
-constexpr int kLongRow = 1024;        // rows longer than this bypass the cells
+constexpr int kMaxLongRow = 1024;     // rows longer than min(this, 2 * strips) bypass the cells
 constexpr int kLongChunk = 512;       // entries per wavefront in long_rows_kernel
 constexpr long long kMaxCells = 1LL << 26;
 
@@ -67,7 +67,7 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 // PASS 0 counts (and lists the long rows), PASS 1 scatters.
 template <int LANES, int PASS>
 __global__ __launch_bounds__(kBlock)
-void bucket_kernel(int num_rows, int num_tiles, int strip_cols, int tile_rows,
+void bucket_kernel(int num_rows, int num_tiles, int strip_cols, int tile_rows, int long_row,
                    const int* __restrict__ row_ptrs, const int* __restrict__ cols,
                    const float* __restrict__ vals,
                    int* __restrict__ cell_counter,            // [num_strips * num_tiles]
@@ -80,7 +80,7 @@ void bucket_kernel(int num_rows, int num_tiles, int strip_cols, int tile_rows,
     const long long row = static_cast<long long>(blockIdx.x) * kRowsPerBlock + threadIdx.x / LANES;
     if (row >= num_rows) return;
     const int begin = row_ptrs[row], end = row_ptrs[row + 1];
-    if (end - begin > kLongRow) {
+    if (end - begin > long_row) {
         if (PASS == 0 && lane == 0) long_rows[atomicAdd(num_long, 1)] = static_cast<int>(row);
         return;
     }
@@ -220,7 +220,7 @@ __device__ __forceinline__ void lds_add(float* slot, float v) {
 
 // Fills the LDS tile with the sums of this tile's rows.  `seed` (may be null) holds the
 // long rows' sums and zeros elsewhere.
-template <int R, int kReduceBlock>
+template <int R, int kReduceBlock, int U>
 __device__ __forceinline__ void tile_accumulate(float* tile, int tile_index, int num_strips, int num_rows,
                                                 const int2* __restrict__ cells_t,
                                                 const float* __restrict__ prod,
@@ -239,37 +239,42 @@ __device__ __forceinline__ void tile_accumulate(float* tile, int tile_index, int
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int kWaves = kReduceBlock / 64;
-    constexpr int kRunsInFlight = 4;      // runs whose first 128 entries are loaded before any add
+    // A group of kRuns runs is processed together, U chunks of 64 entries from each per pass:
+    // all 8 loads of a pass are issued before its first add, and a pass is repeated only while
+    // some run of the group still has entries left (U is picked from the mean run length).
+    constexpr int kRuns = 8 / U;
     const int2* mine = cells_t + static_cast<long long>(tile_index) * num_strips;
-    for (int s0 = wave * 64; s0 < num_strips; s0 += kWaves * 64) {
-        // this wavefront's next 64 runs: one coalesced load of their (begin, length)
+    for (int s0 = 0; s0 < num_strips; s0 += 64) {
+        // the tile's next 64 runs: every wavefront loads their (begin, length) (one coalesced
+        // 512-byte load, L1-shared) and takes every kWaves-th group of kRuns runs
         const int2 meta = s0 + lane < num_strips ? mine[s0 + lane] : make_int2(0, 0);
         const int runs = min(64, num_strips - s0);
-        for (int k0 = 0; k0 < runs; k0 += kRunsInFlight) {
-            int begin[kRunsInFlight], len[kRunsInFlight];
-            float p[kRunsInFlight * 2];
-            int r[kRunsInFlight * 2];
+        for (int k0 = wave * kRuns; k0 < runs; k0 += kWaves * kRuns) {
+            int begin[kRuns], len[kRuns];
+            int longest = 0;
 #pragma unroll
-            for (int j = 0; j < kRunsInFlight; ++j) {      // all loads of the group first ...
+            for (int j = 0; j < kRuns; ++j) {
                 const int k = min(k0 + j, 63);
                 begin[j] = __shfl(meta.x, k, 64);
                 len[j] = k0 + j < runs ? __shfl(meta.y, k, 64) : 0;
+                longest = max(longest, len[j]);
+            }
+            for (int done = 0; done < longest; done += 64 * U) {
+                float p[8];
+                int r[8];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int i = u * 64 + lane;
-                    const bool ok = i < len[j];
-                    p[2 * j + u] = ok ? prod[begin[j] + i] : 0.0f;
-                    r[2 * j + u] = ok ? a_lrow[begin[j] + i] : -1;
+                for (int j = 0; j < kRuns; ++j) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = done + u * 64 + lane;
+                        const bool ok = i < len[j];
+                        p[j * U + u] = ok ? prod[begin[j] + i] : 0.0f;
+                        r[j * U + u] = ok ? a_lrow[begin[j] + i] : -1;
+                    }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < kRunsInFlight * 2; ++u) {      // ... then the adds
-                if (r[u] >= 0) lds_add(&tile[r[u]], p[u]);
-            }
-#pragma unroll
-            for (int j = 0; j < kRunsInFlight; ++j) {      // tails of runs longer than 128 entries
-                for (int i = 128 + lane; i < len[j]; i += 64) {
-                    lds_add(&tile[a_lrow[begin[j] + i]], prod[begin[j] + i]);
+                for (int q = 0; q < 8; ++q) {
+                    if (r[q] >= 0) lds_add(&tile[r[q]], p[q]);
                 }
             }
         }
@@ -277,7 +282,7 @@ __device__ __forceinline__ void tile_accumulate(float* tile, int tile_index, int
     __syncthreads();
 }
 
-template <int R, int kReduceBlock>
+template <int R, int kReduceBlock, int U>
 __global__ __launch_bounds__(kReduceBlock)
 void tiled_reduce_kernel(const int2* __restrict__ cells_t, int num_strips,
                          const float* __restrict__ prod,
@@ -285,13 +290,13 @@ void tiled_reduce_kernel(const int2* __restrict__ cells_t, int num_strips,
                          float* __restrict__ seed,
                          int num_rows, float* __restrict__ y) {
     __shared__ float tile[R];
-    tile_accumulate<R, kReduceBlock>(tile, blockIdx.x, num_strips, num_rows, cells_t, prod, a_lrow, seed);
+    tile_accumulate<R, kReduceBlock, U>(tile, blockIdx.x, num_strips, num_rows, cells_t, prod, a_lrow, seed);
     const long long first = static_cast<long long>(blockIdx.x) * R;
     for (int i = threadIdx.x; i < R && first + i < num_rows; i += kReduceBlock) y[first + i] = tile[i];
 }
 
 // phase 2 with the PageRank update fused into the tile write-out (cf. pr_step_kernel)
-template <int R, int kReduceBlock>
+template <int R, int kReduceBlock, int U>
 __global__ __launch_bounds__(kReduceBlock)
 void tiled_pagerank_reduce_kernel(const int2* __restrict__ cells_t, int num_strips,
                                   const float* __restrict__ prod,
@@ -304,7 +309,7 @@ void tiled_pagerank_reduce_kernel(const int2* __restrict__ cells_t, int num_stri
                                   double* __restrict__ block_partials) {
     if (state->done) return;
     __shared__ float tile[R];
-    tile_accumulate<R, kReduceBlock>(tile, blockIdx.x, num_strips, local_rows, cells_t, prod, a_lrow, seed);
+    tile_accumulate<R, kReduceBlock, U>(tile, blockIdx.x, num_strips, local_rows, cells_t, prod, a_lrow, seed);
 
     const float teleport = __fdiv_rn(1.0f - damping, static_cast<float>(n_global));
     const float dangling_term = __fdiv_rn(__fmul_rn(damping, state->dangling_sum),
@@ -337,7 +342,8 @@ hipError_t launch_bucket(const CSRMatrix* A, const TiledPlan& plan, int* counter
     const int rows_per_block = kBlock / LANES;
     const int grid = (A->num_rows + rows_per_block - 1) / rows_per_block;
     bucket_kernel<LANES, PASS><<<grid, kBlock, 0, s>>>(
-        A->num_rows, plan.num_tiles, plan.strip_cols, plan.tile_rows, A->d_row_ptrs, A->d_col_indices, A->d_values,
+        A->num_rows, plan.num_tiles, plan.strip_cols, plan.tile_rows, plan.long_row, A->d_row_ptrs,
+        A->d_col_indices, A->d_values,
         counter, offs, plan.a_val, plan.a_lcol, plan.a_lrow, plan.long_rows, num_long);
     return hipGetLastError();
 }
@@ -409,16 +415,30 @@ hipError_t launch_expand(const TiledPlan& plan, const float* d_x, hipStream_t s)
     }
 }
 
+template <int R, int U>
+hipError_t launch_reduce_as(const TiledPlan& plan, float* d_y, hipStream_t s) {
+    tiled_reduce_kernel<R, 512, U><<<plan.num_tiles, 512, 0, s>>>(
+        reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_lrow, plan.seed,
+        plan.num_rows, d_y);
+    return hipGetLastError();
+}
+
 template <int R>
 hipError_t launch_reduce(const TiledPlan& plan, float* d_y, hipStream_t s) {
-    const int2* cells = reinterpret_cast<const int2*>(plan.cells_t);
-    if (plan.reduce_block == 1024) {
-        tiled_reduce_kernel<R, 1024><<<plan.num_tiles, 1024, 0, s>>>(cells, plan.num_strips, plan.prod, plan.a_lrow,
-                                                                     plan.seed, plan.num_rows, d_y);
-    } else {
-        tiled_reduce_kernel<R, 512><<<plan.num_tiles, 512, 0, s>>>(cells, plan.num_strips, plan.prod, plan.a_lrow,
-                                                                   plan.seed, plan.num_rows, d_y);
+    switch (plan.run_chunks) {
+        case 1:  return launch_reduce_as<R, 1>(plan, d_y, s);
+        case 2:  return launch_reduce_as<R, 2>(plan, d_y, s);
+        default: return launch_reduce_as<R, 4>(plan, d_y, s);
     }
+}
+
+template <int R, int U>
+hipError_t launch_pagerank_reduce_as(const TiledPlan& plan, int row_offset, int n_global, const float* d_r_old,
+                                     float* d_r_new, const unsigned char* d_dangling, float damping,
+                                     const PrState* d_state, double* d_block_partials, hipStream_t s) {
+    tiled_pagerank_reduce_kernel<R, 512, U><<<plan.num_tiles, 512, 0, s>>>(
+        reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_lrow, plan.seed,
+        plan.num_rows, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state, d_block_partials);
     return hipGetLastError();
 }
 
@@ -426,17 +446,14 @@ template <int R>
 hipError_t launch_pagerank_reduce(const TiledPlan& plan, int row_offset, int n_global, const float* d_r_old,
                                   float* d_r_new, const unsigned char* d_dangling, float damping,
                                   const PrState* d_state, double* d_block_partials, hipStream_t s) {
-    const int2* cells = reinterpret_cast<const int2*>(plan.cells_t);
-    if (plan.reduce_block == 1024) {
-        tiled_pagerank_reduce_kernel<R, 1024><<<plan.num_tiles, 1024, 0, s>>>(
-            cells, plan.num_strips, plan.prod, plan.a_lrow, plan.seed, plan.num_rows, row_offset, n_global,
-            d_r_old, d_r_new, d_dangling, damping, d_state, d_block_partials);
-    } else {
-        tiled_pagerank_reduce_kernel<R, 512><<<plan.num_tiles, 512, 0, s>>>(
-            cells, plan.num_strips, plan.prod, plan.a_lrow, plan.seed, plan.num_rows, row_offset, n_global,
-            d_r_old, d_r_new, d_dangling, damping, d_state, d_block_partials);
+    switch (plan.run_chunks) {
+        case 1:  return launch_pagerank_reduce_as<R, 1>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
+                                                        damping, d_state, d_block_partials, s);
+        case 2:  return launch_pagerank_reduce_as<R, 2>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
+                                                        damping, d_state, d_block_partials, s);
+        default: return launch_pagerank_reduce_as<R, 4>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
+                                                        damping, d_state, d_block_partials, s);
     }
-    return hipGetLastError();
 }
 
 } // namespace
@@ -448,7 +465,7 @@ bool tiled_eligible(const CSRMatrix* A) {
     }();
     static const long long min_cols = [] {
         const char* env = std::getenv("SPMV_TILED_MIN_COLS");
-        return env ? std::atoll(env) : 262144LL;    // below this x sits in L2 and the direct gather wins
+        return env ? std::atoll(env) : 262144LL;      // below ~1 MB of x the direct gather (L2 hits) is as fast
     }();
     if (!enabled || !A || A->num_rows <= 0 || A->nnz < (1 << 20) || A->num_cols < min_cols) return false;
     int w = 0, r = 0;
@@ -476,14 +493,14 @@ hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s) {
     plan->csr_cols = A->d_col_indices;
     plan->csr_vals = A->d_values;
     choose_shape(A, &plan->strip_cols, &plan->tile_rows);
-    plan->reduce_block = 512;
-    if (const char* env = std::getenv("SPMV_TILED_RBLOCK")) {
-        if (std::atoi(env) == 1024) plan->reduce_block = 1024;
-    }
+    plan->run_chunks = 2;
     plan->num_strips = (A->num_cols + plan->strip_cols - 1) / plan->strip_cols;
     plan->num_tiles = (A->num_rows + plan->tile_rows - 1) / plan->tile_rows;
     const long long cells = static_cast<long long>(plan->num_strips) * plan->num_tiles;
-    const long long long_capacity = A->nnz / kLongRow + 1;
+    // A row spreads over the strips; once it averages more than ~2 entries per cell its lanes
+    // start to collide on one LDS word in phase 2, so such rows take the direct path instead.
+    plan->long_row = std::max(64, std::min(kMaxLongRow, 2 * plan->num_strips));
+    const long long long_capacity = A->nnz / plan->long_row + 1;
 
     int *cnt = nullptr, *offs = nullptr, *strip_begin = nullptr, *num_long = nullptr;
     auto cleanup = [&](hipError_t e) {
@@ -517,9 +534,17 @@ hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s) {
     if (e != hipSuccess) return cleanup(e);
     plan->nnz = totals[0];
     plan->num_long = totals[1];
+    {   // 64-entry chunks taken from a run per pass of phase 2: cover the mean run with some slack
+        const long long mean_run = plan->nnz / std::max<long long>(cells, 1);
+        plan->run_chunks = mean_run <= 48 ? 1 : (mean_run <= 110 ? 2 : 4);
+        if (const char* env = std::getenv("SPMV_TILED_CHUNKS")) {
+            const int v = std::atoi(env);
+            if (v == 1 || v == 2 || v == 4) plan->run_chunks = v;
+        }
+    }
 
     if (plan->num_long > 0) {
-        // cut the long rows into wavefront-sized chunks (the list is short: <= nnz / kLongRow rows)
+        // cut the long rows into wavefront-sized chunks (the list is short: <= nnz / long_row rows)
         std::vector<int> rows(plan->num_long);
         e = hipMemcpy(rows.data(), plan->long_rows, rows.size() * sizeof(int), hipMemcpyDeviceToHost);
         std::vector<int> chunks;

@@ -223,12 +223,13 @@ def api_table(spmv, wl, engine, n, k, seed):
     E = wl.uniform_ell_device(seed, 1_000_000, 1_000_000, 32)
     x = wl.vector_device(seed, 1, 1_000_000)
     y = spmv.CudaBuffer(1_000_000)
-    t = wl.time_spmv_ell(E, x, y)
-    avg = float(np.mean(t))
     b = 1_000_000 * 32 * 8 + 1_000_000 * 4 * 2
-    table["c3_ell_1Mx32"] = {"avg_us": round(avg * 1e3, 1), "min_us": round(float(np.min(t)) * 1e3, 1),
-                             "GBps": round(b / avg / 1e6, 1), "frac": round(b / avg / 1e6 / HBM_PEAK_GBS, 4),
-                             "gflops": round(2.0 * 32e6 / avg / 1e6, 1)}
+    for label, tex in (("c3_ell_1Mx32/ell+lds_tiles", True), ("c3_ell_1Mx32/ell", False)):
+        t = wl.time_spmv_ell(E, x, y, use_texture=tex)
+        avg = float(np.mean(t))
+        table[label] = {"avg_us": round(avg * 1e3, 1), "min_us": round(float(np.min(t)) * 1e3, 1),
+                        "GBps": round(b / avg / 1e6, 1), "frac": round(b / avg / 1e6 / HBM_PEAK_GBS, 4),
+                        "gflops": round(2.0 * 32e6 / avg / 1e6, 1)}
     E.close()
     x.release()
     y.release()

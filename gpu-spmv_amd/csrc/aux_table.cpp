@@ -97,8 +97,27 @@ void ell_aux_drop(const void* key) {
     auto& t = ell_table();
     auto it = t.find(key);
     if (it == t.end()) return;
+    if (it->second->tiled) tiled_free(it->second->tiled);
     delete it->second;
     t.erase(it);
+}
+
+const TiledPlan* tiled_plan_for(const ELLMatrix* A, hipStream_t s) {
+    if (!A || !A->d_col_indices || !A->d_values || !tiled_eligible(A)) return nullptr;
+    EllAux* aux = ell_aux_lookup(A->d_col_indices, true);
+    if (aux->tiled && (aux->tiled->num_rows != A->num_rows || aux->tiled->num_cols != A->num_cols)) {
+        tiled_free(aux->tiled);
+        aux->tiled = nullptr;
+        aux->tiled_failed = false;
+    }
+    if (!aux->tiled && !aux->tiled_failed) {
+        if (tiled_build(A, &aux->tiled, s) != hipSuccess) {
+            (void)hipGetLastError();
+            aux->tiled = nullptr;
+            aux->tiled_failed = true;
+        }
+    }
+    return aux->tiled;
 }
 
 } // namespace detail

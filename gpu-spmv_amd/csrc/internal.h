@@ -45,7 +45,10 @@ void    aux_drop(const void* key);
 struct EllAux {
     bool have_nnz = false;
     long long actual_nnz = 0;   // non-padding slots, counted once on the device
+    TiledPlan* tiled = nullptr; // LDS-tiled engine plan built from the slabs (use_texture)
+    bool tiled_failed = false;
 };
+const TiledPlan* tiled_plan_for(const ELLMatrix* A, hipStream_t s);
 EllAux* ell_aux_lookup(const void* key, bool create);
 void    ell_aux_drop(const void* key);
 

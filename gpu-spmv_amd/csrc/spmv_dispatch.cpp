@@ -103,8 +103,13 @@ int check_ell(const ELLMatrix* A, const float* d_x, float* d_y, int vec_size, bo
     return code(SpMVError::SUCCESS);
 }
 
-hipError_t enqueue_ell(const ELLMatrix* A, const float* d_x, float* d_y, hipStream_t stream) {
+hipError_t enqueue_ell(const ELLMatrix* A, const float* d_x, float* d_y, const SpMVConfig* config,
+                       hipStream_t stream) {
     if (A->max_nnz_per_row == 0) return launch_fill_zero(d_y, A->num_rows, stream);
+    // use_texture: x through LDS tiles (gives up the default kernel's CPU summation order)
+    if (config->use_texture) {
+        if (const TiledPlan* plan = tiled_plan_for(A, stream)) return tiled_spmv(*plan, d_x, d_y, stream);
+    }
     return launch_ell(A, d_x, d_y, stream);
 }
 
@@ -197,7 +202,7 @@ SpMVResult spmv_ell(const ELLMatrix* A, const float* d_x, float* d_y,
 
     hipStream_t stream = detail::current_stream();
     result.error_code = detail::timed(stream, &result.elapsed_ms, [&] {
-        return detail::enqueue_ell(A, d_x, d_y, stream);
+        return detail::enqueue_ell(A, d_x, d_y, config, stream);
     });
     if (result.error_code != 0) return result;
 
@@ -228,7 +233,7 @@ int spmv_ell_async(const ELLMatrix* A, const float* d_x, float* d_y,
     const SpMVConfig fallback;
     if (!config) config = &fallback;
     if (!detail::block_size_ok(config)) return detail::code(SpMVError::KERNEL_LAUNCH);
-    return detail::enqueue_ell(A, d_x, d_y, stream) == hipSuccess
+    return detail::enqueue_ell(A, d_x, d_y, config, stream) == hipSuccess
          ? detail::code(SpMVError::SUCCESS) : detail::code(SpMVError::KERNEL_LAUNCH);
 }
 

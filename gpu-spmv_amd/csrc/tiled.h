@@ -49,9 +49,11 @@ struct TiledPlan {
 
 // true when the matrix is worth (and able) to run through the tiled engine
 bool tiled_eligible(const CSRMatrix* A);
+bool tiled_eligible(const ELLMatrix* A);
 
 // builds the plan for A's device arrays (synchronises the stream once)
 hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s);
+hipError_t tiled_build(const ELLMatrix* A, TiledPlan** out, hipStream_t s);   // from the ELL slabs (no long-row path)
 void tiled_free(TiledPlan* plan);
 
 // y = A x

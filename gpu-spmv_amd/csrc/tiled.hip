@@ -101,6 +101,35 @@ void bucket_kernel(int num_rows, int num_tiles, int strip_cols, int tile_rows, i
     }
 }
 
+// ELL source: one thread per row walks the K column-major slabs (padding: col < 0).
+template <int PASS>
+__global__ __launch_bounds__(kBlock)
+void bucket_ell_kernel(int num_rows, int width, int num_tiles, int strip_cols, int tile_rows,
+                       const int* __restrict__ cols, const float* __restrict__ vals,
+                       int* __restrict__ cell_counter, const int* __restrict__ offs,
+                       float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
+                       unsigned short* __restrict__ a_lrow) {
+    const long long row = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x;
+    if (row >= num_rows) return;
+    const int tile = static_cast<int>(row / tile_rows);
+    const unsigned short lrow = static_cast<unsigned short>(row % tile_rows);
+    for (int k = 0; k < width; ++k) {
+        const long long slot = static_cast<long long>(k) * num_rows + row;
+        const int c = cols[slot];
+        if (c < 0) continue;
+        const int strip = c / strip_cols;
+        const long long cell = static_cast<long long>(strip) * num_tiles + tile;
+        if (PASS == 0) {
+            atomicAdd(&cell_counter[cell], 1);
+        } else {
+            const int at = offs[cell] + atomicAdd(&cell_counter[cell], 1);
+            a_val[at] = vals[slot];
+            a_lcol[at] = static_cast<unsigned short>(c - strip * strip_cols);
+            a_lrow[at] = lrow;
+        }
+    }
+}
+
 // out[i] = sum of in[0..i), out[n] = total.  One workgroup of 1024; each thread owns a
 // contiguous chunk (one-time cost, n <= 2^26).
 __global__ __launch_bounds__(1024)
@@ -374,16 +403,16 @@ hipError_t run_long_rows(const TiledPlan& plan, const float* d_x, hipStream_t s)
 // (phase 2 parallelism), strips wide enough that a cell's run averages >= ~96 entries
 // (phase 2 reads one run per cell); when even the widest strip cannot give that (wide
 // shards of a row-partitioned matrix), trade tiles for run length.
-void choose_shape(const CSRMatrix* A, int* strip_cols, int* tile_rows) {
-    auto tiles_for = [&](int r) { return (static_cast<long long>(A->num_rows) + r - 1) / r; };
-    auto strips_for = [&](int w) { return (static_cast<long long>(A->num_cols) + w - 1) / w; };
+void choose_shape(long long num_rows, long long num_cols, long long nnz, int* strip_cols, int* tile_rows) {
+    auto tiles_for = [&](int r) { return (num_rows + r - 1) / r; };
+    auto strips_for = [&](int w) { return (num_cols + w - 1) / w; };
     int r = 8192;
     while (r > 1024 && tiles_for(r) < 1024) r >>= 1;
     int w = 4096;
     for (;;) {
         w = 4096;
-        while (w < 32768 && A->nnz / (strips_for(w) * tiles_for(r)) < 96) w <<= 1;
-        if (A->nnz / (strips_for(w) * tiles_for(r)) >= 96 || r >= 8192) break;
+        while (w < 32768 && nnz / (strips_for(w) * tiles_for(r)) < 96) w <<= 1;
+        if (nnz / (strips_for(w) * tiles_for(r)) >= 96 || r >= 8192) break;
         r <<= 1;
     }
     if (const char* env = std::getenv("SPMV_TILED_STRIP")) {
@@ -458,7 +487,9 @@ hipError_t launch_pagerank_reduce(const TiledPlan& plan, int row_offset, int n_g
 
 } // namespace
 
-bool tiled_eligible(const CSRMatrix* A) {
+namespace {
+
+bool eligible_dims(long long rows, long long cols, long long nnz) {
     static const bool enabled = [] {
         const char* env = std::getenv("SPMV_TILED");
         return !(env && env[0] == '0');
@@ -467,12 +498,48 @@ bool tiled_eligible(const CSRMatrix* A) {
         const char* env = std::getenv("SPMV_TILED_MIN_COLS");
         return env ? std::atoll(env) : 262144LL;      // below ~1 MB of x the direct gather (L2 hits) is as fast
     }();
-    if (!enabled || !A || A->num_rows <= 0 || A->nnz < (1 << 20) || A->num_cols < min_cols) return false;
+    if (!enabled || rows <= 0 || nnz < (1 << 20) || cols < min_cols) return false;
     int w = 0, r = 0;
-    choose_shape(A, &w, &r);
-    const long long strips = (static_cast<long long>(A->num_cols) + w - 1) / w;
-    const long long tiles = (static_cast<long long>(A->num_rows) + r - 1) / r;
-    return strips * tiles <= kMaxCells;
+    choose_shape(rows, cols, nnz, &w, &r);
+    return ((cols + w - 1) / w) * ((rows + r - 1) / r) <= kMaxCells;
+}
+
+// where the entries come from: exactly one of csr / ell is set
+struct Source {
+    const CSRMatrix* csr = nullptr;
+    const ELLMatrix* ell = nullptr;
+    int rows = 0, cols = 0;
+    long long nnz = 0;        // CSR: exact; ELL: slots (upper bound, used for shape / capacity only)
+};
+
+hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s);
+
+} // namespace
+
+bool tiled_eligible(const CSRMatrix* A) {
+    return A && eligible_dims(A->num_rows, A->num_cols, A->nnz);
+}
+
+bool tiled_eligible(const ELLMatrix* A) {
+    return A && eligible_dims(A->num_rows, A->num_cols, static_cast<long long>(A->num_rows) * A->max_nnz_per_row);
+}
+
+hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s) {
+    Source src;
+    src.csr = A;
+    src.rows = A->num_rows;
+    src.cols = A->num_cols;
+    src.nnz = A->nnz;
+    return build_plan(src, out, s);
+}
+
+hipError_t tiled_build(const ELLMatrix* A, TiledPlan** out, hipStream_t s) {
+    Source src;
+    src.ell = A;
+    src.rows = A->num_rows;
+    src.cols = A->num_cols;
+    src.nnz = static_cast<long long>(A->num_rows) * A->max_nnz_per_row;
+    return build_plan(src, out, s);
 }
 
 void tiled_free(TiledPlan* p) {
@@ -483,24 +550,29 @@ void tiled_free(TiledPlan* p) {
     delete p;
 }
 
-hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s) {
+namespace {
+
+hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
+    const CSRMatrix* A = src.csr;          // null for an ELL source (then no long-row path)
     *out = nullptr;
     TiledPlan* plan = new TiledPlan();
-    plan->num_rows = A->num_rows;
-    plan->num_cols = A->num_cols;
-    plan->csr_nnz = A->nnz;
-    plan->csr_row_ptrs = A->d_row_ptrs;
-    plan->csr_cols = A->d_col_indices;
-    plan->csr_vals = A->d_values;
-    choose_shape(A, &plan->strip_cols, &plan->tile_rows);
+    plan->num_rows = src.rows;
+    plan->num_cols = src.cols;
+    plan->csr_nnz = src.nnz;
+    if (A) {
+        plan->csr_row_ptrs = A->d_row_ptrs;
+        plan->csr_cols = A->d_col_indices;
+        plan->csr_vals = A->d_values;
+    }
+    choose_shape(src.rows, src.cols, src.nnz, &plan->strip_cols, &plan->tile_rows);
     plan->run_chunks = 2;
-    plan->num_strips = (A->num_cols + plan->strip_cols - 1) / plan->strip_cols;
-    plan->num_tiles = (A->num_rows + plan->tile_rows - 1) / plan->tile_rows;
+    plan->num_strips = (src.cols + plan->strip_cols - 1) / plan->strip_cols;
+    plan->num_tiles = (src.rows + plan->tile_rows - 1) / plan->tile_rows;
     const long long cells = static_cast<long long>(plan->num_strips) * plan->num_tiles;
     // A row spreads over the strips; once it averages more than ~2 entries per cell its lanes
     // start to collide on one LDS word in phase 2, so such rows take the direct path instead.
-    plan->long_row = std::max(64, std::min(kMaxLongRow, 2 * plan->num_strips));
-    const long long long_capacity = A->nnz / plan->long_row + 1;
+    plan->long_row = A ? std::max(64, std::min(kMaxLongRow, 2 * plan->num_strips)) : 0x7fffffff;
+    const long long long_capacity = src.nnz / plan->long_row + 1;
 
     int *cnt = nullptr, *offs = nullptr, *strip_begin = nullptr, *num_long = nullptr;
     auto cleanup = [&](hipError_t e) {
@@ -517,12 +589,31 @@ hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s) {
     if (e == hipSuccess) e = dev_alloc(&plan->cells_t, 2 * cells);
     if (e != hipSuccess) return cleanup(e);
 
-    const int lanes = std::min(pick_lanes_per_row(static_cast<float>(A->nnz) / A->num_rows) * 4, 64);
+    const int lanes = std::min(pick_lanes_per_row(static_cast<float>(src.nnz) / src.rows) * 4, 64);
+    auto bucket = [&](int pass) -> hipError_t {
+        if (A) {
+            return pass == 0 ? launch_bucket_lanes<0>(lanes, A, *plan, cnt, nullptr, num_long, s)
+                             : launch_bucket_lanes<1>(lanes, A, *plan, cnt, offs, num_long, s);
+        }
+        const ELLMatrix* E = src.ell;
+        const int grid = (E->num_rows + kBlock - 1) / kBlock;
+        if (pass == 0) {
+            bucket_ell_kernel<0><<<grid, kBlock, 0, s>>>(E->num_rows, E->max_nnz_per_row, plan->num_tiles,
+                                                        plan->strip_cols, plan->tile_rows, E->d_col_indices,
+                                                        E->d_values, cnt, nullptr, nullptr, nullptr, nullptr);
+        } else {
+            bucket_ell_kernel<1><<<grid, kBlock, 0, s>>>(E->num_rows, E->max_nnz_per_row, plan->num_tiles,
+                                                        plan->strip_cols, plan->tile_rows, E->d_col_indices,
+                                                        E->d_values, cnt, offs, plan->a_val, plan->a_lcol,
+                                                        plan->a_lrow);
+        }
+        return hipGetLastError();
+    };
 
     // pass 0: cell sizes + the list of long rows
     e = hipMemsetAsync(cnt, 0, cells * sizeof(int), s);
     if (e == hipSuccess) e = hipMemsetAsync(num_long, 0, sizeof(int), s);
-    if (e == hipSuccess) e = launch_bucket_lanes<0>(lanes, A, *plan, cnt, nullptr, num_long, s);
+    if (e == hipSuccess) e = bucket(0);
     if (e == hipSuccess) {
         exclusive_scan_kernel<<<1, 1024, 0, s>>>(cnt, cells, offs);
         e = hipGetLastError();
@@ -543,7 +634,7 @@ hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s) {
         }
     }
 
-    if (plan->num_long > 0) {
+    if (A && plan->num_long > 0) {
         // cut the long rows into wavefront-sized chunks (the list is short: <= nnz / long_row rows)
         std::vector<int> rows(plan->num_long);
         e = hipMemcpy(rows.data(), plan->long_rows, rows.size() * sizeof(int), hipMemcpyDeviceToHost);
@@ -588,7 +679,7 @@ hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s) {
 
     // pass 1: scatter the short rows' entries into their cells
     e = hipMemsetAsync(cnt, 0, cells * sizeof(int), s);
-    if (e == hipSuccess) e = launch_bucket_lanes<1>(lanes, A, *plan, cnt, offs, num_long, s);
+    if (e == hipSuccess) e = bucket(1);
     if (e == hipSuccess) {
         const int grid = static_cast<int>(std::min<long long>((cells + kBlock) / kBlock, 4096));
         cell_table_kernel<<<grid, kBlock, 0, s>>>(offs, plan->num_strips, plan->num_tiles,
@@ -629,6 +720,8 @@ hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s) {
     *out = plan;
     return hipSuccess;
 }
+
+} // namespace
 
 hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipStream_t s) {
     hipError_t e = run_long_rows(plan, d_x, s);

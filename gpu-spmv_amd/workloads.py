@@ -130,14 +130,15 @@ def uniform_ell_device(seed, n_rows, n_cols, k, stream=None) -> DeviceELL:
     return E
 
 
-def time_spmv_ell(E, d_x, d_y, warmup=5, runs=20):
+def time_spmv_ell(E, d_x, d_y, warmup=5, runs=20, use_texture=False):
     handle = E.handle if isinstance(E, DeviceELL) else E
     cols = handle.contents.num_cols
+    cfg = SpMVConfig(kernel_type=SpMVConfig.ELL_KERNEL, use_texture=use_texture)
     for _ in range(warmup):
-        _check(spmv_ell(handle, d_x, d_y, None, cols).error_code, "spmv_ell")
+        _check(spmv_ell(handle, d_x, d_y, cfg, cols).error_code, "spmv_ell")
     times = []
     for _ in range(runs):
-        r = spmv_ell(handle, d_x, d_y, None, cols)
+        r = spmv_ell(handle, d_x, d_y, cfg, cols)
         _check(r.error_code, "spmv_ell")
         times.append(float(r.elapsed_ms))
     return times

@@ -301,3 +301,30 @@ def test_use_texture_on_small_matrix_keeps_direct_kernels(gpu, oracle):
     res = gpu.spmv_csr(A, d_x, d_y, gpu.SpMVConfig(kernel_type=0, use_texture=True), 20000)
     np.testing.assert_array_equal(d_y.copyToHost(5000), oracle.spmv_csr(rp, ci, va, x))
     gpu.csr_destroy(A)
+
+
+def test_ell_through_the_tiled_engine(gpu, oracle):
+    """spmv_ell with use_texture: the plan is built from the column-major slabs (padding skipped)."""
+    import ctypes
+    rows, cols, k = 300_000, 400_000, 12
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, k + 1, size=rows)
+    lens[7] = k
+    rp, ci, va = gpu.synth.stratified_csr(8, 0, lens, cols)
+    kk, ecols, evals = oracle.ell_from_csr(rp, ci, va)
+    x = gpu.synth.vector(8, 1, cols)
+    want = oracle.spmv_ell(rows, kk, ecols, evals, x)
+    E = gpu.ell_create(rows, cols, kk)
+    ctypes.memmove(E.contents.col_indices, ecols.ctypes.data, ecols.nbytes)
+    ctypes.memmove(E.contents.values, evals.ctypes.data, evals.nbytes)
+    assert gpu.ell_to_gpu(E) == 0
+    d_x, d_y = gpu.CudaBuffer(cols), gpu.CudaBuffer(rows)
+    d_x.copyFromHost(x, cols)
+    cfg = gpu.SpMVConfig(kernel_type=gpu.SpMVConfig.ELL_KERNEL, use_texture=True)
+    for _ in range(2):
+        res = gpu.spmv_ell(E, d_x, d_y, cfg, cols)
+        assert res.error_code == 0
+    assert reorder_err(rp, ci, va, x, want, d_y.copyToHost(rows)) <= REORDER_TOL
+    res = gpu.spmv_ell(E, d_x, d_y, None, cols)              # default config: CPU order, bit-exact
+    np.testing.assert_array_equal(d_y.copyToHost(rows), want)
+    gpu.ell_destroy(E)

@@ -59,6 +59,7 @@ constexpr int kMinItemEntries = 4096;
 constexpr int kMaxLongRow = 1024;     // rows longer than min(this, 2 * strips) bypass the cells
 constexpr int kLongChunk = 512;       // entries per wavefront in long_rows_kernel
 constexpr long long kMaxCells = 1LL << 26;
+constexpr long long kTargetRun = 128;   // wanted mean entries per cell (run length seen by phase 2)
 
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
@@ -400,7 +401,7 @@ hipError_t run_long_rows(const TiledPlan& plan, const float* d_x, hipStream_t s)
 }
 
 // W / R for a matrix: as many row tiles as it takes to fill the chip several times over
-// (phase 2 parallelism), strips wide enough that a cell's run averages >= ~96 entries
+// (phase 2 parallelism), strips wide enough that a cell's run averages >= ~128 entries
 // (phase 2 reads one run per cell); when even the widest strip cannot give that (wide
 // shards of a row-partitioned matrix), trade tiles for run length.
 void choose_shape(long long num_rows, long long num_cols, long long nnz, int* strip_cols, int* tile_rows) {
@@ -411,8 +412,11 @@ void choose_shape(long long num_rows, long long num_cols, long long nnz, int* st
     int w = 4096;
     for (;;) {
         w = 4096;
-        while (w < 32768 && nnz / (strips_for(w) * tiles_for(r)) < 96) w <<= 1;
-        if (nnz / (strips_for(w) * tiles_for(r)) >= 96 || r >= 8192) break;
+        while (w < 32768 && nnz / (strips_for(w) * tiles_for(r)) < kTargetRun) w <<= 1;
+        const bool long_enough = nnz / (strips_for(w) * tiles_for(r)) >= kTargetRun;
+        // taller tiles lengthen the runs but cost phase-2 parallelism: keep >= ~600 tiles
+        // (measured on a 1.25 M x 10 M shard: 611 tiles / 107-entry runs 88 us, 306 / 213 105 us)
+        if (long_enough || r >= 8192 || tiles_for(2 * r) < 600) break;
         r <<= 1;
     }
     if (const char* env = std::getenv("SPMV_TILED_STRIP")) {
@@ -627,7 +631,7 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     plan->num_long = totals[1];
     {   // 64-entry chunks taken from a run per pass of phase 2: cover the mean run with some slack
         const long long mean_run = plan->nnz / std::max<long long>(cells, 1);
-        plan->run_chunks = mean_run <= 48 ? 1 : (mean_run <= 110 ? 2 : 4);
+        plan->run_chunks = mean_run <= 48 ? 1 : (mean_run <= 384 ? 2 : 4);
         if (const char* env = std::getenv("SPMV_TILED_CHUNKS")) {
             const int v = std::atoi(env);
             if (v == 1 || v == 2 || v == 4) plan->run_chunks = v;

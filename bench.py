@@ -84,8 +84,8 @@ def main():
 
     n, k = args.rows, args.nnz_per_row
     nnz_total = n * k
-    shard_len, row_begin, row_end = prd.shard_bounds(n, world, rank)
-    local_rows = row_end - row_begin
+    layout = prd.Layout(n, world, rank)
+    shard_len, row_begin, local_rows = layout.shard_len, layout.row_begin, layout.local_rows
 
     # ---- build this rank's rows in HBM (torch owns the memory; the C ABI fills it) ----
     stream = torch.cuda.current_stream().cuda_stream
@@ -102,9 +102,11 @@ def main():
     spmv.lib().spmv_c_reciprocal_values(local_rows * k, cols.data_ptr(), counts.data_ptr(), vals.data_ptr(), stream)
     del counts
     cols_v, vals_v = cols[: local_rows * k], vals[: local_rows * k]
+    if world > 1:
+        cols_v.copy_(layout.remap_columns(cols_v))     # node ids -> positions in the padded rank vector
 
-    engine = prd.HipEngine(row_ptrs, cols_v, vals_v, row_begin, n)
-    pr = prd.ShardedPageRank(engine, n, rank, world).prepare()
+    engine = prd.HipEngine(row_ptrs, cols_v, vals_v, layout)
+    pr = prd.ShardedPageRank(engine, layout).prepare()
     pr.reset()
 
     damping, never = 0.85, 0.0          # tolerance 0: the loop never converges, every step does full work
@@ -138,7 +140,7 @@ def main():
     value = bytes_per_step * args.steps / elapsed / 1e9
 
     # ---- roofline of the dominant kernel: the fused step kernel alone, HIP events on its stream ----
-    local_bytes = csr_bytes(local_rows, n, local_rows * k)
+    local_bytes = csr_bytes(local_rows, n, local_rows * k)     # this rank's share of the algorithmic bytes
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
     for a, b in ev:
         a.record()
@@ -172,7 +174,7 @@ def main():
                    "nnz": nnz_total, "avg_nnz_per_row": k,
                    "kernel": "VECTOR_CSR with x staged through LDS tiles (fused PageRank step)" if tiled
                              else "VECTOR_CSR direct gather (fused PageRank step)",
-                   "parallelism": "row-shard x%d%s" % (world, "" if world == 1 else " + RCCL all-reduce(2 f64) + all-gather(%d f32/rank)" % shard_len)},
+                   "parallelism": "row-shard x%d%s" % (world, "" if world == 1 else " + one RCCL all-gather per step (%d f32/rank, partial sums in the slice tails)" % layout.stride)},
         "gflops": round(2.0 * nnz_total * args.steps / elapsed / 1e9, 1),
         "pagerank_iters_per_sec": round(args.steps / elapsed, 2),
         "frac_of_hbm_peak_whole_job": round(value / (HBM_PEAK_GBS * world), 4),

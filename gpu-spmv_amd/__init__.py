@@ -193,6 +193,7 @@ _SIGNATURES = {
     "spmv_c_pr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "spmv_c_pr_reduce": (c_int, [c_void_p, c_void_p, c_void_p]),
     "spmv_c_pr_commit": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
+    "spmv_c_pr_commit_gathered": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_float, c_void_p]),
     "spmv_c_pr_status_get": (c_int, [c_void_p, POINTER(PrStatus), c_void_p]),
     "spmv_c_pr_column_sums": (c_int, [POINTER(CSRMatrix), c_void_p, c_void_p]),
     "spmv_c_pr_mask_from_column_sums": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -289,8 +289,9 @@ void spmv_c_pagerank_top_k(const spmv_c_pagerank_result* result, int num_nodes, 
 spmv_c_pr_shard* spmv_c_pr_shard_create(const spmv_c_csr* A_local, int row_offset, int n_global,
                                         const uint8_t* d_dangling_mask) {
     const CSRMatrix* A = cxx(A_local);
-    if (!A || row_offset < 0 || n_global <= 0 || !d_dangling_mask ||
-        row_offset + A->num_rows > n_global ||
+    // the rank vector is indexed by column (num_cols long, possibly padded); n_global is the true node count
+    if (!A || row_offset < 0 || n_global <= 0 || !d_dangling_mask || n_global > A->num_cols ||
+        static_cast<long long>(row_offset) + A->num_rows > A->num_cols ||
         (A->num_rows > 0 && !A->d_row_ptrs) ||
         (A->nnz > 0 && (!A->d_col_indices || !A->d_values))) {
         return nullptr;
@@ -347,6 +348,15 @@ int spmv_c_pr_reduce(spmv_c_pr_shard* h, double* d_sums, void* hip_stream) {
 int spmv_c_pr_commit(spmv_c_pr_shard* h, const double* d_sums, float tolerance, void* hip_stream) {
     if (!h || !d_sums) return kInvalidArgument;
     return launch_code(detail::pr_commit(h->shard, d_sums, tolerance, as_stream(hip_stream)));
+}
+
+int spmv_c_pr_commit_gathered(spmv_c_pr_shard* h, const float* d_gathered, int world, int64_t stride,
+                              int64_t shard_len, float tolerance, void* hip_stream) {
+    if (!h || !d_gathered || world < 1 || stride < shard_len + 4 || (stride & 1) || (shard_len & 1)) {
+        return kInvalidArgument;
+    }
+    return launch_code(detail::pr_commit_gathered(h->shard, d_gathered, world, stride, shard_len, tolerance,
+                                                  as_stream(hip_stream)));
 }
 
 int spmv_c_pr_status_get(spmv_c_pr_shard* h, spmv_c_pr_status* out, void* hip_stream) {

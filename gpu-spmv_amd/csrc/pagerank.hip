@@ -118,6 +118,29 @@ __global__ void pr_commit_kernel(const double* __restrict__ sums, float toleranc
     }
 }
 
+// Multi-rank form: every rank's (residual^2, dangling mass) pair travels in the 16-byte tail
+// of its slice of the all-gathered vector; all ranks fold the pairs in rank order (same
+// result everywhere, no separate all-reduce).
+__global__ void pr_commit_gathered_kernel(const float* __restrict__ gathered, int world,
+                                          long long stride, long long shard_len, float tolerance,
+                                          PrState* __restrict__ state) {
+    if (state->done) return;
+    double res2 = 0.0, mass = 0.0;
+    for (int p = 0; p < world; ++p) {
+        const double* tail = reinterpret_cast<const double*>(gathered + p * stride + shard_len);
+        res2 += tail[0];
+        mass += tail[1];
+    }
+    const float residual = static_cast<float>(sqrt(res2));
+    state->iterations += 1;
+    state->final_residual = residual;
+    state->dangling_sum = static_cast<float>(mass);
+    if (residual < tolerance) {
+        state->converged = 1;
+        state->done = 1;
+    }
+}
+
 __global__ __launch_bounds__(kBlock)
 void pr_fill_kernel(float* __restrict__ r, size_t n, float value) {
     for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
@@ -204,6 +227,12 @@ hipError_t pr_reduce(const PrShard& sh, double* d_sums, hipStream_t s) {
 
 hipError_t pr_commit(const PrShard& sh, const double* d_sums, float tolerance, hipStream_t s) {
     pr_commit_kernel<<<1, 1, 0, s>>>(d_sums, tolerance, sh.d_state);
+    return hipGetLastError();
+}
+
+hipError_t pr_commit_gathered(const PrShard& sh, const float* d_gathered, int world, long long stride,
+                              long long shard_len, float tolerance, hipStream_t s) {
+    pr_commit_gathered_kernel<<<1, 1, 0, s>>>(d_gathered, world, stride, shard_len, tolerance, sh.d_state);
     return hipGetLastError();
 }
 

@@ -44,6 +44,8 @@ hipError_t pr_step(const PrShard& shard, const float* d_r_old, float* d_r_new, f
                    hipStream_t s);
 hipError_t pr_reduce(const PrShard& shard, double* d_sums /*[2]*/, hipStream_t s);
 hipError_t pr_commit(const PrShard& shard, const double* d_sums, float tolerance, hipStream_t s);
+hipError_t pr_commit_gathered(const PrShard& shard, const float* d_gathered, int world, long long stride,
+                              long long shard_len, float tolerance, hipStream_t s);
 hipError_t pr_fill(float* d_r, size_t n, float value, hipStream_t s);
 hipError_t pr_column_sums(long long nnz, const int* d_cols, const float* d_vals, int n_cols,
                           float* d_col_sums, hipStream_t s);

@@ -5,22 +5,28 @@ exchange step the path has.
 The reference has no multi-GPU code; its single-GPU host loop is
 src/pagerank.cu:50-153.  Here rank p owns the contiguous row block
 [p*shard_len, (p+1)*shard_len) of the n x n matrix and keeps a full-length rank
-vector.  Per iteration:
+vector.  Per iteration (world > 1):
 
-    engine.step(r_old, r_new)   fused HIP kernel over the local rows: SpMV, damping /
-                                teleport update, partial residual^2 and dangling mass
-    all_reduce(sums)            2 doubles (RCCL)               — only when world > 1
-    engine.commit(sums)         device-side residual / convergence flag / next dangling mass
-    all_gather(r_new)           shard_len floats per rank, in place — only when world > 1
+    engine.step(r_old, r_new)   HIP kernels over the local rows: SpMV, damping / teleport
+                                update, partial residual^2 and dangling mass; the two partial
+                                sums (doubles) are written into the 16-byte TAIL of this
+                                rank's slice of r_new
+    all_gather(r_new)           ONE collective per iteration (RCCL): shard_len + 4 floats per
+                                rank, in place — delivers every slice and every rank's partials
+    engine.commit_gathered()    every rank folds the P partial pairs in rank order (identical
+                                result everywhere): residual, convergence flag, next dangling mass
 
-Nothing else crosses ranks; the SpMV itself needs no collective (replicated x,
-sharded A).  The compute engine is the C ABI of libspmv_amd.so (HipEngine); the
-loop itself is backend-agnostic so the world_size-2 gloo tests drive it with a
-test double on CPU tensors.
+so the vector lives in a padded layout: node g sits at (g // shard_len) * stride + g % shard_len
+with stride = shard_len + 4; the shard's column indices are remapped to that layout once
+(`Layout.remap_columns`), which costs nothing per iteration.  With world == 1 there is no
+padding, no collective, and commit() consumes the local sums directly.
+
+Nothing else crosses ranks; the SpMV itself needs no collective (replicated x, sharded A).
+The compute engine is the C ABI of libspmv_amd.so (HipEngine); the loop itself is
+backend-agnostic so the world_size-2 gloo tests drive it with a test double on CPU tensors.
 """
 from __future__ import annotations
 
-import ctypes
 from ctypes import byref, c_void_p
 
 import numpy as np
@@ -29,13 +35,46 @@ import torch.distributed as dist
 
 from . import PrStatus, csr_destroy, csr_wrap_device, lib
 
+TAIL = 4   # floats appended to every slice when world > 1 (two doubles)
+
+
+class Layout:
+    """Where node g lives in the (padded) rank vector, and who owns which rows."""
+
+    def __init__(self, n: int, world: int = 1, rank: int = 0):
+        self.n, self.world, self.rank = n, world, rank
+        shard_len = (n + world - 1) // world
+        if world > 1 and shard_len % 2:
+            shard_len += 1                      # keeps every tail 8-byte aligned
+        self.shard_len = shard_len
+        self.stride = shard_len + (TAIL if world > 1 else 0)
+        self.padded = self.stride * world
+        self.row_begin = min(rank * shard_len, n)
+        self.row_end = min(self.row_begin + shard_len, n)
+        self.local_rows = self.row_end - self.row_begin
+        self.row_offset = rank * self.stride    # position of this rank's first node in the vector
+
+    def remap_columns(self, cols):
+        """Column (= node) indices -> positions in the padded vector (numpy or torch int32)."""
+        if self.world == 1:
+            return cols
+        return cols + (cols // self.shard_len) * TAIL
+
+    def positions(self) -> np.ndarray:
+        """Padded position of every node 0..n-1."""
+        g = np.arange(self.n, dtype=np.int64)
+        return (g // self.shard_len) * self.stride + g % self.shard_len
+
+    def tail_slice(self, rank=None):
+        rank = self.rank if rank is None else rank
+        start = rank * self.stride + self.shard_len
+        return slice(start, start + TAIL)
+
 
 def shard_bounds(n: int, world: int, rank: int):
-    """Equal contiguous row blocks: (shard_len, row_begin, row_end); the last shards may be short or empty."""
-    shard_len = (n + world - 1) // world
-    begin = min(rank * shard_len, n)
-    end = min(begin + shard_len, n)
-    return shard_len, begin, end
+    """(shard_len, row_begin, row_end) of Layout(n, world, rank)."""
+    lay = Layout(n, world, rank)
+    return lay.shard_len, lay.row_begin, lay.row_end
 
 
 def initial_dangling_mass(num_dangling: int, n: int) -> float:
@@ -52,18 +91,18 @@ def initial_dangling_mass(num_dangling: int, n: int) -> float:
 class HipEngine:
     """The shard engine behind include/spmv_c.h (spmv_c_pr_*), on torch CUDA(HIP) tensors.
 
-    row_ptrs (rebased to 0), col_indices, values: this rank's rows as device tensors.
-    Kernels are enqueued on torch's current stream, so they order with the RCCL calls.
+    row_ptrs (rebased to 0), col_indices (already remapped by Layout.remap_columns), values:
+    this rank's rows as device tensors.  Kernels are enqueued on torch's current stream, so
+    they order with the RCCL calls.
     """
 
-    def __init__(self, row_ptrs, col_indices, values, row_begin, n):
+    def __init__(self, row_ptrs, col_indices, values, layout: Layout):
         assert row_ptrs.is_cuda and row_ptrs.dtype == torch.int32
+        assert row_ptrs.numel() - 1 == layout.local_rows
         self.device = row_ptrs.device
-        self.n = n
-        self.row_begin = row_begin
-        self.local_rows = row_ptrs.numel() - 1
+        self.layout = layout
         self._keep = (row_ptrs, col_indices, values)
-        self._A = csr_wrap_device(self.local_rows, n, int(col_indices.numel()), row_ptrs.data_ptr(),
+        self._A = csr_wrap_device(layout.local_rows, layout.padded, int(col_indices.numel()), row_ptrs.data_ptr(),
                                   col_indices.data_ptr() if col_indices.numel() else 0,
                                   values.data_ptr() if values.numel() else 0)
         if self._A is None:
@@ -82,31 +121,43 @@ class HipEngine:
             raise RuntimeError(f"{what}: {lib().spmv_c_error_string(status).decode()}")
 
     def column_sums(self) -> torch.Tensor:
-        sums = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+        """Column sums of this shard's stored values, in padded coordinates."""
+        sums = torch.zeros(self.layout.padded, dtype=torch.float32, device=self.device)
         self._check(lib().spmv_c_pr_column_sums(self._A, c_void_p(sums.data_ptr()), self._stream()), "pr_column_sums")
         return sums
 
     def set_dangling_mask(self, mask: torch.Tensor) -> None:
-        assert mask.dtype == torch.uint8 and mask.numel() >= self.n
+        assert mask.dtype == torch.uint8 and mask.numel() >= self.layout.padded
         self._mask = mask
         if self._shard:
             lib().spmv_c_pr_shard_destroy(self._shard)
-        self._shard = lib().spmv_c_pr_shard_create(self._A, self.row_begin, self.n, c_void_p(mask.data_ptr()))
+        # the engine divides by the TRUE node count; the matrix header carries the padded width
+        self._shard = lib().spmv_c_pr_shard_create(self._A, self.layout.row_offset, self.layout.n,
+                                                   c_void_p(mask.data_ptr()))
         if not self._shard:
             raise RuntimeError("spmv_c_pr_shard_create failed")
 
     def reset(self, dangling_sum: float) -> None:
         self._check(lib().spmv_c_pr_reset(self._shard, dangling_sum, self._stream()), "pr_reset")
 
-    def step(self, r_old: torch.Tensor, r_new: torch.Tensor, damping: float) -> torch.Tensor:
+    def step(self, r_old: torch.Tensor, r_new: torch.Tensor, damping: float, sums_out: torch.Tensor = None):
+        """Enqueue one step; the two partial sums land in `sums_out` (2 doubles: a view into the
+        tail of this rank's slice when world > 1) or in the engine's own buffer."""
+        target = self._sums if sums_out is None else sums_out
         self._check(lib().spmv_c_pr_step(self._shard, c_void_p(r_old.data_ptr()), c_void_p(r_new.data_ptr()),
                                          damping, self._stream()), "pr_step")
-        self._check(lib().spmv_c_pr_reduce(self._shard, c_void_p(self._sums.data_ptr()), self._stream()), "pr_reduce")
-        return self._sums
+        self._check(lib().spmv_c_pr_reduce(self._shard, c_void_p(target.data_ptr()), self._stream()), "pr_reduce")
+        return target
 
     def commit(self, sums: torch.Tensor, tolerance: float) -> None:
         self._check(lib().spmv_c_pr_commit(self._shard, c_void_p(sums.data_ptr()), tolerance, self._stream()),
                     "pr_commit")
+
+    def commit_gathered(self, gathered: torch.Tensor, tolerance: float) -> None:
+        lay = self.layout
+        self._check(lib().spmv_c_pr_commit_gathered(self._shard, c_void_p(gathered.data_ptr()), lay.world,
+                                                    lay.stride, lay.shard_len, tolerance, self._stream()),
+                    "pr_commit_gathered")
 
     def status(self):
         out = PrStatus()
@@ -126,42 +177,49 @@ class ShardedPageRank:
     """The host loop.  `engine` is a HipEngine (product) or any object with the same
     methods (the CPU test double in tests/test_distributed_gloo.py)."""
 
-    def __init__(self, engine, n, rank=0, world=1, group=None, device=None):
-        self.engine, self.n, self.rank, self.world, self.group = engine, n, rank, world, group
-        self.shard_len, self.row_begin, self.row_end = shard_bounds(n, world, rank)
-        self.padded = self.shard_len * world
+    def __init__(self, engine, layout: Layout, group=None, device=None):
+        self.engine, self.layout, self.group = engine, layout, group
+        self.n, self.rank, self.world = layout.n, layout.rank, layout.world
         self.device = device if device is not None else getattr(engine, "device", torch.device("cpu"))
-        self.r = [torch.zeros(self.padded, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.r = [torch.zeros(layout.padded, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._pos = torch.from_numpy(layout.positions()).to(self.device)
         self.num_dangling = None
+
+    def _my_slice(self, buf):
+        lay = self.layout
+        return buf[lay.row_offset: lay.row_offset + lay.stride]
+
+    def _my_tail(self, buf):
+        return buf[self.layout.tail_slice()].view(torch.float64)
 
     # -- one-time setup: dangling mask from the globally summed column sums ------------
     def prepare(self):
         sums = self.engine.column_sums()
         if self.world > 1:
             dist.all_reduce(sums, group=self.group)
-        mask = torch.zeros(self.padded, dtype=torch.uint8, device=self.device)
-        mask[: self.n] = (sums[: self.n] == 0).to(torch.uint8)
+        mask = torch.zeros(self.layout.padded, dtype=torch.uint8, device=self.device)
+        mask[self._pos] = (sums[self._pos] == 0).to(torch.uint8)
         self.num_dangling = int(mask.sum().item())
         self.engine.set_dangling_mask(mask)
         return self
 
     def reset(self):
-        start = np.float32(1.0) / np.float32(self.n)
+        start = float(np.float32(1.0) / np.float32(self.n))
         for buf in self.r:
             buf.zero_()
-            buf[: self.n] = float(start)
+            buf[self._pos] = start
         self.engine.reset(initial_dangling_mass(self.num_dangling, self.n))
 
     def iterate(self, k, damping, tolerance):
-        """Enqueue `step` iterations k (0-based); r[k & 1] -> r[(k + 1) & 1]."""
+        """Enqueue iteration k (0-based): r[k & 1] -> r[(k + 1) & 1]."""
         r_old, r_new = self.r[k & 1], self.r[(k + 1) & 1]
-        sums = self.engine.step(r_old, r_new, damping)
-        if self.world > 1:
-            dist.all_reduce(sums, group=self.group)
-        self.engine.commit(sums, tolerance)
-        if self.world > 1:
-            mine = r_new[self.rank * self.shard_len:(self.rank + 1) * self.shard_len]
-            dist.all_gather_into_tensor(r_new, mine, group=self.group)
+        if self.world == 1:
+            sums = self.engine.step(r_old, r_new, damping)
+            self.engine.commit(sums, tolerance)
+            return
+        self.engine.step(r_old, r_new, damping, self._my_tail(r_new))
+        dist.all_gather_into_tensor(r_new, self._my_slice(r_new), group=self.group)
+        self.engine.commit_gathered(r_new, tolerance)
 
     def run(self, damping=0.85, tolerance=1e-6, max_iterations=100, check_every=1):
         """Full PageRank; returns (ranks[n] float32 numpy, iterations, final_residual, converged).
@@ -173,7 +231,7 @@ class ShardedPageRank:
             if (k + 1) % check_every == 0 and self.engine.status()[3]:
                 break
         iterations, residual, converged, _ = self.engine.status()
-        last = self.r[iterations & 1][: self.n].to("cpu").numpy().copy()
+        last = self.r[iterations & 1][self._pos].to("cpu").numpy().copy()
         total = np.float32(last.sum(dtype=np.float64))
         if total > 0:
             last = (last / total).astype(np.float32)

@@ -197,11 +197,13 @@ void spmv_c_pagerank_top_k(const spmv_c_pagerank_result* result, int num_nodes, 
                            spmv_c_topk_node* top_k);
 
 /* ---- PageRank shard engine (extension: the row-sharded multi-GPU loop) ----
- * One rank owns rows [row_offset, row_offset + A_local->num_rows) of the
- * n_global x n_global matrix (A_local: device CSR, row_ptrs rebased to 0,
- * num_cols = n_global) and full-length device vectors.  Per iteration the host
- * calls step -> reduce -> [all-reduce d_sums over ranks] -> commit ->
- * [all-gather the new slice].  All calls enqueue on `hip_stream` and return. */
+ * One rank owns A_local->num_rows consecutive rows of the n_global-node matrix (A_local: device
+ * CSR, row_ptrs rebased to 0) and full-length device vectors of A_local->num_cols floats, which
+ * the column indices address; its nodes sit at [row_offset, row_offset + num_rows) of those
+ * vectors (num_cols may exceed n_global when slices carry padding, see pagerank_dist.py).
+ * Per iteration: step -> reduce (partials into the slice tail) -> [all-gather] ->
+ * commit_gathered; or with one rank: step -> reduce -> commit.  All calls enqueue on
+ * `hip_stream` and return. */
 typedef struct spmv_c_pr_shard spmv_c_pr_shard;   /* opaque */
 typedef struct spmv_c_pr_status {                 /* device-side state, copied out */
     float   dangling_sum;
@@ -221,6 +223,10 @@ int spmv_c_pr_step(spmv_c_pr_shard* shard, const float* d_r_old, float* d_r_new,
                    void* hip_stream);
 int spmv_c_pr_reduce(spmv_c_pr_shard* shard, double* d_sums /*[2]*/, void* hip_stream);
 int spmv_c_pr_commit(spmv_c_pr_shard* shard, const double* d_sums, float tolerance, void* hip_stream);
+/* multi-rank commit without an all-reduce: rank p's two partial sums (as doubles) sit in the 16-byte
+ * tail of its slice, d_gathered[p * stride + shard_len ...]; stride >= shard_len + 4, both even */
+int spmv_c_pr_commit_gathered(spmv_c_pr_shard* shard, const float* d_gathered, int world, int64_t stride,
+                              int64_t shard_len, float tolerance, void* hip_stream);
 int spmv_c_pr_status_get(spmv_c_pr_shard* shard, spmv_c_pr_status* out, void* hip_stream); /* syncs */
 /* dangling-node detection on the device: accumulate this shard's column sums
  * (atomic adds into d_col_sums[n_global]); after the sums of all shards are

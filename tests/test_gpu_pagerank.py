@@ -131,8 +131,9 @@ def test_shard_engine_single_rank_equals_pagerank(gpu, oracle):
     A = upload(gpu, rp, ci, va, n)
     direct = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
     dev = torch.device("cuda:0")
-    eng = prd.HipEngine(torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev), 0, n)
-    pr = prd.ShardedPageRank(eng, n).prepare()
+    lay = prd.Layout(n)
+    eng = prd.HipEngine(torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev), lay)
+    pr = prd.ShardedPageRank(eng, lay).prepare()
     ranks, iters, res, conv = pr.run(0.85, 1e-6, 100, check_every=3)
     assert pr.num_dangling == int(oracle.dangling_mask(rp, ci, va, n).sum()) >= 2
     assert conv == direct.converged and iters == direct.iterations
@@ -142,44 +143,54 @@ def test_shard_engine_single_rank_equals_pagerank(gpu, oracle):
 
 
 def test_two_shards_on_one_gpu_equal_one_shard(gpu, oracle):
-    """Row-shard simulator on one device: two engines stepping halves of the matrix, the
-    host playing the collective (sum of partials, slices written in place), must match the
-    unsharded run.  Not bit for bit: a shard's rebased row_ptrs change which 16-byte group an
-    entry falls in, hence the order of a row's fp32 sum (last-ulp differences)."""
+    """Row-shard simulator on one device: two HipEngines own the halves of the matrix in the
+    padded world-2 layout; the host plays the all-gather (copies each engine's slice, tail
+    included, into the other's vector), then both commit from the gathered tails.  Must match
+    the unsharded run — not bit for bit: a shard's rebased row_ptrs change which 16-byte group
+    an entry falls in, hence the order of a row's fp32 sum (last-ulp differences)."""
     torch = pytest.importorskip("torch")
     prd = importlib.import_module("gpu-spmv_amd.pagerank_dist")
-    n = 40_000
+    n = 40_001                                   # odd: shard_len is rounded up to even, last shard short
     rp, ci, va = graph(gpu, n, 10, 8, dangling=(11,))
     dev = torch.device("cuda:0")
 
-    def engine(b, e):
+    def engine(lay):
+        b, e = lay.row_begin, lay.row_end
         lrp = torch.from_numpy((rp[b:e + 1] - rp[b]).astype(np.int32)).to(dev)
-        return prd.HipEngine(lrp, torch.from_numpy(ci[rp[b]:rp[e]]).to(dev), torch.from_numpy(va[rp[b]:rp[e]]).to(dev), b, n)
+        lci = torch.from_numpy(lay.remap_columns(ci[rp[b]:rp[e]]).astype(np.int32)).to(dev)
+        return prd.HipEngine(lrp, lci, torch.from_numpy(va[rp[b]:rp[e]]).to(dev), lay)
 
-    whole, lo, hi = engine(0, n), engine(0, n // 2), engine(n // 2, n)
-    pr = prd.ShardedPageRank(whole, n).prepare()
-    mask = torch.zeros(n, dtype=torch.uint8, device=dev)
-    mask[:n] = ((lo.column_sums() + hi.column_sums()) == 0).to(torch.uint8)
+    whole_lay = prd.Layout(n)
+    lays = [prd.Layout(n, 2, r) for r in range(2)]
+    whole = prd.ShardedPageRank(engine(whole_lay), whole_lay).prepare()
+    shards = [prd.ShardedPageRank(engine(l), l) for l in lays]
+    sums = shards[0].engine.column_sums() + shards[1].engine.column_sums()      # the all-reduce of prepare()
     num_dangling = int(oracle.dangling_mask(rp, ci, va, n).sum())
-    assert int(mask.sum()) == pr.num_dangling == num_dangling >= 1
-    lo.set_dangling_mask(mask)
-    hi.set_dangling_mask(mask)
-    start = prd.initial_dangling_mass(num_dangling, n)
-    pr.reset()
-    lo.reset(start)
-    hi.reset(start)
-    r = [torch.full((n,), 1.0 / n, dtype=torch.float32, device=dev) for _ in range(2)]
+    for sp in shards:
+        mask = torch.zeros(sp.layout.padded, dtype=torch.uint8, device=dev)
+        mask[sp._pos] = (sums[sp._pos] == 0).to(torch.uint8)
+        sp.num_dangling = int(mask.sum().item())
+        assert sp.num_dangling == whole.num_dangling == num_dangling >= 1
+        sp.engine.set_dangling_mask(mask)
+        sp.reset()
+    whole.reset()
     for k in range(6):
-        pr.iterate(k, 0.85, 0.0)
-        old, new = r[k & 1], r[(k + 1) & 1]
-        s = lo.step(old, new, 0.85).clone() + hi.step(old, new, 0.85)
-        lo.commit(s, 0.0)
-        hi.commit(s, 0.0)
-        torch.testing.assert_close(new, pr.r[(k + 1) & 1][:n], rtol=2e-6, atol=0)
-    assert lo.status()[0] == hi.status()[0] == whole.status()[0] == 6
-    assert abs(lo.status()[1] - whole.status()[1]) <= 1e-12 + 1e-6 * whole.status()[1]
-    for e in (whole, lo, hi):
-        e.close()
+        whole.iterate(k, 0.85, 0.0)
+        news = [sp.r[(k + 1) & 1] for sp in shards]
+        for sp in shards:
+            sp.engine.step(sp.r[k & 1], sp.r[(k + 1) & 1], 0.85, sp._my_tail(sp.r[(k + 1) & 1]))
+        for src in (0, 1):                                                      # the all-gather
+            sl = slice(lays[src].row_offset, lays[src].row_offset + lays[src].stride)
+            news[1 - src][sl] = news[src][sl]
+        for sp in shards:
+            sp.engine.commit_gathered(sp.r[(k + 1) & 1], 0.0)
+        torch.testing.assert_close(news[0], news[1], rtol=0, atol=0)           # both ranks hold the same vector
+        torch.testing.assert_close(news[0][shards[0]._pos], whole.r[(k + 1) & 1][whole._pos], rtol=2e-6, atol=0)
+    st = [sp.engine.status() for sp in shards] + [whole.engine.status()]
+    assert [x[0] for x in st] == [6, 6, 6]
+    assert st[0][1] == st[1][1] and abs(st[0][1] - st[2][1]) <= 1e-12 + 1e-6 * st[2][1]
+    for sp in shards + [whole]:
+        sp.engine.close()
 
 
 def test_pagerank_through_the_tiled_engine(gpu, oracle):

@@ -74,13 +74,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the SpMV path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    spmv.lib().spmv_c_set_device(local_rank)
+    # SPMV_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 code path
+    # on a single-GPU box (numbers from such a run mean nothing); the real thing is RCCL.
+    backend = os.environ.get("SPMV_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    spmv.lib().spmv_c_set_device(dev_index)
     spmv.require_gpu()
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     n, k = args.rows, args.nnz_per_row
     nnz_total = n * k

@@ -24,8 +24,8 @@
 //        lanes/clk/CU measured), so the add is a compare-and-swap on the word's integer
 //        image (3.5 lanes/clk/CU measured; race-free for any row multiplicity).
 //   long rows (more than min(1024, 2 x strips) entries) would make many lanes fight over one
-//        LDS word; they are left out of the cells and summed by one wavefront each
-//        (direct gather) into a side vector that seeds the tiles.
+//        LDS word; they are left out of the cells and summed in 512-entry chunks by extra
+//        wavefronts of the phase-1 grid (direct gather) into a side vector that seeds the tiles.
 //
 // HBM traffic per entry: 6 B read + 4 B written in phase 1, 6 B read in phase 2
 // (16 B vs CSR's 8 B) — but all of it is streamed, which beats one 64-byte random
@@ -57,7 +57,7 @@ using namespace dev;
 constexpr int kMaxItemEntries = 65536;   // phase-1 work item size bounds (entries)
 constexpr int kMinItemEntries = 4096;
 constexpr int kMaxLongRow = 1024;     // rows longer than min(this, 2 * strips) bypass the cells
-constexpr int kLongChunk = 512;       // entries per wavefront in long_rows_kernel
+constexpr int kLongChunk = 512;       // entries per wavefront of the long-row path
 constexpr long long kMaxCells = 1LL << 26;
 constexpr long long kTargetRun = 128;   // wanted mean entries per cell (run length seen by phase 2)
 
@@ -175,17 +175,45 @@ void cell_table_kernel(const int* __restrict__ offs, int num_strips, int num_til
 }
 
 // ------------------------------------------------------------------------ phase 1 ----
+// Rows too long for the cells are cut into chunks of kLongChunk entries; one wavefront per
+// chunk sums it by direct gather and adds the sum atomically into seed[row].  seed is zero on
+// entry (zeroed at build; phase 2 re-zeroes what it consumes).  These wavefronts ride in extra
+// workgroups at the head of the phase-1 grid, so they overlap the expansion at no launch cost.
+struct LongRows {
+    const int* chunks;        // (row, begin, end) triples over the CSR arrays
+    int num_chunks;
+    long long nnz;
+    const int* cols;
+    const float* vals;
+    float* seed;
+};
+
+__device__ __forceinline__ void long_row_chunk(const LongRows& lr, int which, const float* __restrict__ x) {
+    if (which >= lr.num_chunks) return;
+    const int row = lr.chunks[3 * which];
+    float acc = row_partial_dot<64>(lr.chunks[3 * which + 1], lr.chunks[3 * which + 2], threadIdx.x & 63, lr.nnz,
+                                    lr.cols, lr.vals, x);
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&lr.seed[row], acc);
+}
+
 template <int W, int kExpandBlock>
 __global__ __launch_bounds__(kExpandBlock)
-void tiled_expand_kernel(const int* __restrict__ items,
+void tiled_expand_kernel(const int* __restrict__ items, int long_blocks,
                          const float* __restrict__ a_val,
                          const unsigned short* __restrict__ a_lcol,
                          const float* __restrict__ x, int num_cols,
-                         float* __restrict__ prod) {
+                         float* __restrict__ prod, LongRows long_rows) {
+    if (static_cast<int>(blockIdx.x) < long_blocks) {     // the long-row workgroups go first (latency-bound)
+        constexpr int kPerBlock = kExpandBlock / 64;
+        long_row_chunk(long_rows, blockIdx.x * kPerBlock + (threadIdx.x >> 6), x);
+        return;
+    }
     __shared__ float xs[W];
-    const int strip = items[3 * blockIdx.x];
-    const int begin = items[3 * blockIdx.x + 1];
-    const int end = items[3 * blockIdx.x + 2];
+    const int item = blockIdx.x - long_blocks;
+    const int strip = items[3 * item];
+    const int begin = items[3 * item + 1];
+    const int end = items[3 * item + 2];
 
     const long long base = static_cast<long long>(strip) * W;
     const int width = static_cast<int>(min(static_cast<long long>(W), num_cols - base));
@@ -218,21 +246,6 @@ void tiled_expand_kernel(const int* __restrict__ items,
             for (int k = max(q, begin); k < min(q + 4, end); ++k) prod[k] = a_val[k] * xs[a_lcol[k]];
         }
     }
-}
-
-// rows too long for the cells: cut into chunks of kLongChunk entries, one wavefront per
-// chunk (direct gather), chunk sums added atomically into seed[row].  seed is zero on entry
-// (zeroed at build; phase 2 re-zeroes what it consumes).
-__global__ __launch_bounds__(kBlock)
-void long_rows_kernel(const int* __restrict__ chunks /*(row, begin, end) triples*/, int num_chunks,
-                      long long nnz, const int* __restrict__ cols, const float* __restrict__ vals,
-                      const float* __restrict__ x, float* __restrict__ seed) {
-    const int which = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (which >= num_chunks) return;
-    const int row = chunks[3 * which];
-    float acc = row_partial_dot<64>(chunks[3 * which + 1], chunks[3 * which + 2], threadIdx.x & 63, nnz, cols, vals, x);
-    acc = group_sum<64>(acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&seed[row], acc);
 }
 
 // ------------------------------------------------------------------------ phase 2 ----
@@ -392,14 +405,6 @@ hipError_t launch_bucket_lanes(int lanes, const CSRMatrix* A, const TiledPlan& p
     }
 }
 
-hipError_t run_long_rows(const TiledPlan& plan, const float* d_x, hipStream_t s) {
-    if (plan.num_long_chunks == 0) return hipSuccess;
-    const int per_block = kBlock / 64;
-    long_rows_kernel<<<(plan.num_long_chunks + per_block - 1) / per_block, kBlock, 0, s>>>(
-        plan.long_chunks, plan.num_long_chunks, plan.csr_nnz, plan.csr_cols, plan.csr_vals, d_x, plan.seed);
-    return hipGetLastError();
-}
-
 // W / R for a matrix: as many row tiles as it takes to fill the chip several times over
 // (phase 2 parallelism), strips wide enough that a cell's run averages >= ~128 entries
 // (phase 2 reads one run per cell); when even the widest strip cannot give that (wide
@@ -433,13 +438,15 @@ void choose_shape(long long num_rows, long long num_cols, long long nnz, int* st
 
 template <int W, int BLOCK>
 hipError_t launch_expand_as(const TiledPlan& plan, const float* d_x, hipStream_t s) {
-    tiled_expand_kernel<W, BLOCK><<<plan.num_items, BLOCK, 0, s>>>(plan.items, plan.a_val, plan.a_lcol, d_x,
-                                                                   plan.num_cols, plan.prod);
+    const LongRows lr{plan.long_chunks, plan.num_long_chunks, plan.csr_nnz, plan.csr_cols, plan.csr_vals, plan.seed};
+    const int long_blocks = (plan.num_long_chunks + BLOCK / 64 - 1) / (BLOCK / 64);
+    tiled_expand_kernel<W, BLOCK><<<plan.num_items + long_blocks, BLOCK, 0, s>>>(
+        plan.items, long_blocks, plan.a_val, plan.a_lcol, d_x, plan.num_cols, plan.prod, lr);
     return hipGetLastError();
 }
 
 hipError_t launch_expand(const TiledPlan& plan, const float* d_x, hipStream_t s) {
-    if (plan.num_items == 0) return hipSuccess;
+    if (plan.num_items == 0 && plan.num_long_chunks == 0) return hipSuccess;
     switch (plan.strip_cols) {
         case 4096:  return launch_expand_as<4096, 512>(plan, d_x, s);
         case 8192:  return launch_expand_as<8192, 512>(plan, d_x, s);
@@ -728,8 +735,7 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
 } // namespace
 
 hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipStream_t s) {
-    hipError_t e = run_long_rows(plan, d_x, s);
-    if (e == hipSuccess) e = launch_expand(plan, d_x, s);
+    const hipError_t e = launch_expand(plan, d_x, s);       // phase 1 + the long rows
     if (e != hipSuccess) return e;
     switch (plan.tile_rows) {
         case 1024: return launch_reduce<1024>(plan, d_y, s);
@@ -745,8 +751,7 @@ hipError_t tiled_pagerank_step(const TiledPlan& plan, int row_offset, int n_glob
                                const PrState* d_state, double* d_block_partials, hipStream_t s) {
     // After convergence the reduce kernel returns before touching r_new; the other kernels
     // then only rewrite scratch (product stream, seed vector), which nothing reads.
-    hipError_t e = run_long_rows(plan, d_r_old, s);
-    if (e == hipSuccess) e = launch_expand(plan, d_r_old, s);
+    const hipError_t e = launch_expand(plan, d_r_old, s);   // phase 1 + the long rows
     if (e != hipSuccess) return e;
     switch (plan.tile_rows) {
         case 1024: return launch_pagerank_reduce<1024>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,

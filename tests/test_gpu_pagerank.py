@@ -205,3 +205,27 @@ def test_pagerank_through_the_tiled_engine(gpu, oracle):
     assert r.converged == conv and abs(r.iterations - iters) <= 1
     compare(r.ranks, want)
     gpu.csr_destroy(A)
+
+
+def test_config5_pagerank_full_size_invariants(gpu):
+    """BASELINE config 5: PageRank (d = 0.85, tol = 1e-6) on the 10 M-node / 160 M-edge
+    column-stochastic matrix built in HBM.  Size-independent properties (reference
+    tests/test_pagerank.cu:18-77): ranks >= 0, sum = 1 (1e-4), converged => residual < tol;
+    plus a fixed-point check: one more device SpMV step leaves the ranks in place."""
+    wl = importlib.import_module("gpu-spmv_amd.workloads")
+    n = 10_000_000
+    A = wl.uniform_csr_device(42, n, n, 16)
+    wl.make_column_stochastic(A)
+    r = gpu.pagerank(A.handle, gpu.PageRankConfig(0.85, 1e-6, 100))
+    assert r.converged and r.final_residual < 1e-6 and 2 <= r.iterations <= 100
+    assert (r.ranks >= 0).all() and abs(float(r.ranks.sum(dtype=np.float64)) - 1.0) < 1e-4
+    # fixed point: r ~ d * A r + (1 - d) / n + d * dangling_mass / n; all terms from the device SpMV
+    d_r, d_y = gpu.CudaBuffer(n), gpu.CudaBuffer(n)
+    d_r.copyFromHost(r.ranks, n)
+    assert gpu.spmv_csr(A.handle, d_r, d_y, gpu.SpMVConfig(1, 256, True), n).error_code == 0
+    y = d_y.copyToHost(n).astype(np.float64)
+    counts = np.bincount(A.col_indices.copyToHost(A.nnz), minlength=n)
+    dangling = float(r.ranks[counts == 0].sum(dtype=np.float64))
+    nxt = 0.85 * y + 0.85 * dangling / n + 0.15 / n
+    assert np.sqrt(np.sum((nxt - r.ranks) ** 2)) < 5e-6
+    A.close()

@@ -328,3 +328,86 @@ def test_ell_through_the_tiled_engine(gpu, oracle):
     res = gpu.spmv_ell(E, d_x, d_y, None, cols)              # default config: CPU order, bit-exact
     np.testing.assert_array_equal(d_y.copyToHost(rows), want)
     gpu.ell_destroy(E)
+
+
+# ------------------------------------------------ BASELINE configs 3, 4, 5 at full size --------
+def _device_inputs(gpu, A, cols, tag):
+    wl = __import__("importlib").import_module("gpu-spmv_amd.workloads")
+    x = wl.vector_device(42, tag, cols)
+    return x, x.copyToHost(cols)
+
+
+def test_config5_full_size_oracle_parity_and_linearity(gpu, oracle):
+    """BASELINE config 5's matrix (10 M x 10 M, 160 M entries, built in HBM): the LDS-tiled engine
+    and the direct vector kernel against the CPU oracle on the full matrix, plus linearity."""
+    import importlib
+    wl = importlib.import_module("gpu-spmv_amd.workloads")
+    n, k = 10_000_000, 16
+    A = wl.uniform_csr_device(42, n, n, k)
+    rp, ci, va = A.to_host()
+    assert (np.diff(rp) == k).all() and ci.min() >= 0 and ci.max() < n
+    x1d, x1 = _device_inputs(gpu, A, n, 1)
+    x2d, x2 = _device_inputs(gpu, A, n, 2)
+    want = oracle.spmv_csr(rp, ci, va, x1)
+    y = gpu.CudaBuffer(n)
+    got = {}
+    for name, cfg in (("tiled", gpu.SpMVConfig(1, 256, True)), ("vector", gpu.SpMVConfig(1, 256, False))):
+        res = gpu.spmv_csr(A.handle, x1d, y, cfg, n)
+        assert res.error_code == 0
+        got[name] = y.copyToHost(n)
+        assert reorder_err(rp, ci, va, x1, want, got[name]) <= REORDER_TOL, name
+    assert gpu.csr_has_tiled_plan(A.handle)
+    # linearity through the tiled engine: A(2 x1 + 0.5 x2) = 2 A x1 + 0.5 A x2
+    res = gpu.spmv_csr(A.handle, x2d, y, gpu.SpMVConfig(1, 256, True), n)
+    y2 = y.copyToHost(n)
+    x3d = gpu.CudaBuffer(n)
+    x3d.copyFromHost((2.0 * x1 + 0.5 * x2).astype(np.float32), n)
+    res = gpu.spmv_csr(A.handle, x3d, y, gpu.SpMVConfig(1, 256, True), n)
+    lin = 2.0 * got["tiled"].astype(np.float64) + 0.5 * y2.astype(np.float64)
+    assert np.max(np.abs(lin - y.copyToHost(n))) <= 1e-4 * max(1.0, float(np.max(np.abs(lin))))
+    A.close()
+
+
+def test_config4_full_size_power_law(gpu, oracle):
+    """BASELINE config 4 (1 M rows, Pareto lengths, one row of 10 000): selector picks MERGE_PATH;
+    merge-path, the tiled engine and vector-CSR all match the oracle."""
+    import importlib
+    wl = importlib.import_module("gpu-spmv_amd.workloads")
+    n = 1_000_000
+    A = wl.power_law_csr_device(42, n, n)
+    rp, ci, va = A.to_host()
+    cfg = gpu.spmv_auto_config(A.handle)
+    assert cfg.kernel_type == gpu.SpMVConfig.MERGE_PATH and cfg.use_texture == 1
+    st = gpu.csr_compute_stats(A.handle)
+    assert st.max_nnz_per_row == 10000 and st.skewness >= 10
+    xd, x = _device_inputs(gpu, A, n, 4)
+    want = oracle.spmv_csr(rp, ci, va, x)
+    y = gpu.CudaBuffer(n)
+    for c in (cfg, gpu.SpMVConfig(2, 256, False), gpu.SpMVConfig(1, 256, False)):
+        assert gpu.spmv_csr(A.handle, xd, y, c, n).error_code == 0
+        assert reorder_err(rp, ci, va, x, want, y.copyToHost(n)) <= REORDER_TOL
+    A.close()
+
+
+def test_config3_full_size_ell(gpu, oracle):
+    """BASELINE config 3 (ELL 1 M x 1 M, K = 32, no padding): default path bit-exact against the
+    oracle, use_texture path within the reorder tolerance."""
+    import importlib
+    wl = importlib.import_module("gpu-spmv_amd.workloads")
+    n, k = 1_000_000, 32
+    E = wl.uniform_ell_device(42, n, n, k)
+    ecols = E.col_indices.copyToHost(n * k)
+    evals = E.values.copyToHost(n * k)
+    rp, ci, va = gpu.synth.uniform_csr(42, 0, 4096, n, k)          # the generator's CSR twin, first rows
+    np.testing.assert_array_equal(ecols.reshape(k, n)[:, :4096].T.reshape(-1), ci)
+    xd, x = _device_inputs(gpu, E, n, 3)
+    want = oracle.spmv_ell(n, k, ecols, evals, x)
+    y = gpu.CudaBuffer(n)
+    assert gpu.spmv_ell(E.handle, xd, y, None, n).error_code == 0
+    np.testing.assert_array_equal(y.copyToHost(n), want)
+    cfg = gpu.SpMVConfig(gpu.SpMVConfig.ELL_KERNEL, 256, True)
+    assert gpu.spmv_ell(E.handle, xd, y, cfg, n).error_code == 0
+    got = y.copyToHost(n)
+    scale = np.abs(evals.reshape(k, n).astype(np.float64) * x[ecols.reshape(k, n)]).sum(axis=0)
+    assert np.max(np.abs(got - want) / np.maximum(np.maximum(np.abs(want), scale), 1e-30)) <= REORDER_TOL
+    E.close()

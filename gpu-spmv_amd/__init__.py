@@ -159,6 +159,7 @@ _SIGNATURES = {
     "spmv_c_ell_destroy": (None, [POINTER(ELLMatrix)]),
     "spmv_c_ell_from_dense": (c_int, [POINTER(ELLMatrix), c_void_p, c_int, c_int]),
     "spmv_c_ell_from_csr": (c_int, [POINTER(ELLMatrix), POINTER(CSRMatrix)]),
+    "spmv_c_ell_from_csr_gpu": (c_int, [POINTER(ELLMatrix), POINTER(CSRMatrix)]),
     "spmv_c_ell_to_dense": (c_int, [POINTER(ELLMatrix), c_void_p]),
     "spmv_c_ell_get_element": (c_float, [POINTER(ELLMatrix), c_int, c_int]),
     "spmv_c_ell_to_gpu": (c_int, [POINTER(ELLMatrix)]),
@@ -459,6 +460,11 @@ def ell_from_dense(ell, dense, rows, cols) -> int:
 
 def ell_from_csr(ell, csr) -> int:
     return lib().spmv_c_ell_from_csr(ell, csr)
+
+
+def ell_from_csr_gpu(ell, csr) -> int:
+    """Extension: CSR -> ELL on the device (device slabs only; ell_from_gpu mirrors them to the host)."""
+    return lib().spmv_c_ell_from_csr_gpu(ell, csr)
 
 
 def ell_to_dense(ell) -> np.ndarray:

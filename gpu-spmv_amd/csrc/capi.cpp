@@ -168,6 +168,7 @@ int spmv_c_ell_from_dense(spmv_c_ell* ell, const float* dense, int rows, int col
     return ell_from_dense(cxx(ell), dense, rows, cols);
 }
 int spmv_c_ell_from_csr(spmv_c_ell* ell, const spmv_c_csr* csr) { return ell_from_csr(cxx(ell), cxx(csr)); }
+int spmv_c_ell_from_csr_gpu(spmv_c_ell* ell, const spmv_c_csr* csr) { return ell_from_csr_gpu(cxx(ell), cxx(csr)); }
 int spmv_c_ell_to_dense(const spmv_c_ell* ell, float* dense) { return ell_to_dense(cxx(ell), dense); }
 float spmv_c_ell_get_element(const spmv_c_ell* mat, int row, int col) {
     return ell_get_element(cxx(mat), row, col);

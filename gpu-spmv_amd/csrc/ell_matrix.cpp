@@ -116,6 +116,46 @@ int ell_from_csr(ELLMatrix* ell, const CSRMatrix* csr) {
     return detail::code(SpMVError::SUCCESS);
 }
 
+// Extension (SURVEY.md §8f "next" #1): the same conversion on the device, from the CSR's
+// device arrays straight into freshly allocated device slabs — no host pass, no PCIe.
+// The ELL matrix ends up device-only (host slabs released); ell_from_gpu can fetch them.
+int ell_from_csr_gpu(ELLMatrix* ell, const CSRMatrix* csr) {
+    if (!ell || !csr) return detail::code(SpMVError::INVALID_ARGUMENT);
+    if (csr->num_rows > 0 && (!csr->d_row_ptrs || (csr->nnz > 0 && (!csr->d_col_indices || !csr->d_values)))) {
+        return detail::code(SpMVError::INVALID_FORMAT);
+    }
+    hipStream_t stream = detail::current_stream();
+    int widest = 0, shortest = 0;
+    if (csr->num_rows > 0 &&
+        detail::device_row_stats(csr->d_row_ptrs, csr->num_rows, &widest, &shortest, stream) != hipSuccess) {
+        return detail::code(SpMVError::KERNEL_LAUNCH);
+    }
+    ell_free_gpu(ell);
+    adopt_shape(ell, csr->num_rows, csr->num_cols, 0);      // drops the old host slabs
+    ell->max_nnz_per_row = widest;
+    ell->owns_device_memory = true;
+    const size_t n = slots(ell);
+    if (n > 0) {
+        if (hipMalloc(reinterpret_cast<void**>(&ell->d_values), n * sizeof(float)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&ell->d_col_indices), n * sizeof(int)) != hipSuccess) {
+            ell_free_gpu(ell);
+            return detail::code(SpMVError::CUDA_MALLOC);
+        }
+        if (detail::launch_ell_from_csr(csr, widest, ell->d_col_indices, ell->d_values, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) {
+            ell_free_gpu(ell);
+            return detail::code(SpMVError::KERNEL_LAUNCH);
+        }
+        // host slabs of the right size, filled on demand by ell_from_gpu
+        ell->values = new float[n];
+        ell->col_indices = new int[n];
+        std::fill_n(ell->values, n, 0.0f);
+        std::fill_n(ell->col_indices, n, -1);
+    }
+    ell->owns_device_memory = true;
+    return detail::code(SpMVError::SUCCESS);
+}
+
 int ell_to_dense(const ELLMatrix* ell, float* dense) {
     if (!ell || !dense) return detail::code(SpMVError::INVALID_ARGUMENT);
 

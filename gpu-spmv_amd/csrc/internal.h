@@ -61,6 +61,8 @@ hipError_t launch_csr_merge(const CSRMatrix* A, CsrAux* aux, const float* d_x, f
                             hipStream_t s);
 hipError_t launch_ell(const ELLMatrix* A, const float* d_x, float* d_y, hipStream_t s);
 hipError_t launch_fill_zero(float* d_y, size_t n, hipStream_t s);
+hipError_t launch_ell_from_csr(const CSRMatrix* csr, int width, int* d_ell_cols, float* d_ell_vals,
+                               hipStream_t s);
 hipError_t device_count_ell_nnz(const ELLMatrix* A, long long* out, hipStream_t s);
 hipError_t device_row_stats(const int* d_row_ptrs, int num_rows, int* max_out, int* min_out,
                             hipStream_t s);

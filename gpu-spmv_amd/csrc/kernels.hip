@@ -393,6 +393,24 @@ void row_stats_kernel(const int* __restrict__ row_ptrs, int num_rows, int* __res
     }
 }
 
+// CSR -> column-major ELL on the device (reference src/ell_matrix.cpp:139-156 is a host loop):
+// LANES lanes per row copy its entries into slabs k = 0.. and pad the rest with (-1, 0.0f).
+__global__ __launch_bounds__(kBlock)
+void ell_from_csr_kernel(int num_rows, int width, const int* __restrict__ row_ptrs,
+                         const int* __restrict__ cols, const float* __restrict__ vals,
+                         int* __restrict__ ell_cols, float* __restrict__ ell_vals) {
+    for (long long row = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; row < num_rows;
+         row += static_cast<long long>(gridDim.x) * kBlock) {
+        const int begin = row_ptrs[row];
+        const int len = row_ptrs[row + 1] - begin;
+        for (int k = 0; k < width; ++k) {
+            const long long slot = static_cast<long long>(k) * num_rows + row;    // coalesced over rows
+            ell_cols[slot] = k < len ? cols[begin + k] : -1;
+            ell_vals[slot] = k < len ? vals[begin + k] : 0.0f;
+        }
+    }
+}
+
 inline int capped_grid(long long work_items, int per_block) {
     const long long blocks = (work_items + per_block - 1) / per_block;
     return static_cast<int>(std::max(1LL, std::min<long long>(blocks, kMaxResidentBlocks)));
@@ -488,6 +506,14 @@ hipError_t launch_ell(const ELLMatrix* A, const float* d_x, float* d_y, hipStrea
         ell_kernel_x1<<<grid, kBlock, 0, s>>>(A->num_rows, A->max_nnz_per_row, A->d_col_indices,
                                               A->d_values, d_x, d_y);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_ell_from_csr(const CSRMatrix* csr, int width, int* d_ell_cols, float* d_ell_vals,
+                               hipStream_t s) {
+    if (csr->num_rows == 0 || width == 0) return hipSuccess;
+    ell_from_csr_kernel<<<capped_grid(csr->num_rows, kBlock), kBlock, 0, s>>>(
+        csr->num_rows, width, csr->d_row_ptrs, csr->d_col_indices, csr->d_values, d_ell_cols, d_ell_vals);
     return hipGetLastError();
 }
 

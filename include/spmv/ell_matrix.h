@@ -34,6 +34,9 @@ void ell_destroy(ELLMatrix* mat);
 
 int ell_from_dense(ELLMatrix* ell, const float* dense, int rows, int cols);
 int ell_from_csr(ELLMatrix* ell, const CSRMatrix* csr);
+// extension: the conversion on the device (csr must be uploaded); fills ell's device slabs
+// only — call ell_from_gpu to mirror them into the host slabs
+int ell_from_csr_gpu(ELLMatrix* ell, const CSRMatrix* csr);
 int ell_to_dense(const ELLMatrix* ell, float* dense);
 float ell_get_element(const ELLMatrix* mat, int row, int col);
 

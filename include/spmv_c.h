@@ -153,6 +153,8 @@ spmv_c_ell* spmv_c_ell_create(int rows, int cols, int max_nnz_per_row);
 void spmv_c_ell_destroy(spmv_c_ell* mat);
 int spmv_c_ell_from_dense(spmv_c_ell* ell, const float* dense, int rows, int cols);
 int spmv_c_ell_from_csr(spmv_c_ell* ell, const spmv_c_csr* csr);
+/* extension (device-side conversion, no host pass): see ell_from_csr_gpu in spmv/ell_matrix.h */
+int spmv_c_ell_from_csr_gpu(spmv_c_ell* ell, const spmv_c_csr* csr);
 int spmv_c_ell_to_dense(const spmv_c_ell* ell, float* dense);
 float spmv_c_ell_get_element(const spmv_c_ell* mat, int row, int col);
 int spmv_c_ell_to_gpu(spmv_c_ell* mat);

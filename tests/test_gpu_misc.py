@@ -130,3 +130,35 @@ def test_async_entry_point_on_a_stream(gpu, oracle):
     stream.synchronize()
     np.testing.assert_array_equal(ty.cpu().numpy(), oracle.spmv_csr(rp, ci, va, x))   # last launch: scalar
     gpu.csr_destroy(A)
+
+
+def test_ell_from_csr_on_the_device_matches_the_host_conversion(gpu, oracle):
+    """device-side ell_from_csr equals the reference's host conversion
+    (src/ell_matrix.cpp:111-159) slab for slab, and feeds spmv_ell directly."""
+    rng = np.random.default_rng(11)
+    lens = rng.integers(0, 20, size=30001)
+    lens[123] = 37
+    rp, ci, va = gpu.synth.stratified_csr(3, 0, lens, 50000)
+    A = gpu.csr_from_arrays(30001, 50000, rp, ci, va)
+    assert gpu.csr_to_gpu(A) == 0
+    E = gpu.ell_create(0, 0, 0)
+    assert gpu.ell_from_csr_gpu(E, A) == 0
+    e = E.contents
+    assert (e.num_rows, e.num_cols, e.max_nnz_per_row) == (30001, 50000, 37) and e.d_values and e.owns_device_memory
+    assert gpu.ell_from_gpu(E) == 0
+    k, want_cols, want_vals = oracle.ell_from_csr(rp, ci, va)
+    got_cols, got_vals = gpu.ell_host_arrays(E)
+    np.testing.assert_array_equal(got_cols, want_cols)
+    np.testing.assert_array_equal(got_vals.view(np.uint32), want_vals.view(np.uint32))
+    x = gpu.synth.vector(3, 3, 50000)
+    d_x, d_y = gpu.CudaBuffer(50000), gpu.CudaBuffer(30001)
+    d_x.copyFromHost(x, 50000)
+    assert gpu.spmv_ell(E, d_x, d_y, None, 50000).error_code == 0
+    np.testing.assert_array_equal(d_y.copyToHost(30001), oracle.spmv_ell(30001, k, want_cols, want_vals, x))
+    gpu.ell_destroy(E)
+    B = gpu.csr_create(5, 5, 0)                              # not uploaded -> INVALID_FORMAT
+    E2 = gpu.ell_create(0, 0, 0)
+    assert gpu.ell_from_csr_gpu(E2, B) == gpu.SpMVError.INVALID_FORMAT
+    gpu.ell_destroy(E2)
+    gpu.csr_destroy(B)
+    gpu.csr_destroy(A)

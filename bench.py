@@ -189,6 +189,14 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_extras:
+        # the drop-in pagerank() call end to end on the same matrix (d = 0.85, tol = 1e-6, <= 100 iterations)
+        t0 = time.perf_counter()
+        full = spmv.pagerank(engine._A, spmv.PageRankConfig(0.85, 1e-6, 100))
+        t_full = time.perf_counter() - t0
+        result["pagerank_api"] = {"iterations": full.iterations, "converged": bool(full.converged),
+                                  "final_residual": full.final_residual, "seconds_total": round(t_full, 4),
+                                  "ms_per_iteration_incl_setup": round(t_full / max(full.iterations, 1) * 1e3, 3),
+                                  "rank_sum": float(full.ranks.sum(dtype=np.float64))}
         result["spmv_csr_api"] = api_table(spmv, wl, engine, n, k, args.seed)
         result["cpu_baseline"] = cpu_baseline(spmv, row_ptrs, cols_v, vals_v, n, nnz_total)
     elif rank == 0:

@@ -57,6 +57,9 @@ void    ell_aux_drop(const void* key);
 hipError_t launch_csr_scalar(const CSRMatrix* A, const float* d_x, float* d_y, hipStream_t s);
 hipError_t launch_csr_vector(const CSRMatrix* A, const float* d_x, float* d_y,
                              int lanes_per_row, hipStream_t s);
+int vector_ldsx_grid(const CSRMatrix* A);      // 0 = x-in-LDS variant not worthwhile for this matrix
+hipError_t launch_csr_vector_ldsx(const CSRMatrix* A, const float* d_x, float* d_y, int lanes_per_row,
+                                  int grid, hipStream_t s);
 hipError_t launch_csr_merge(const CSRMatrix* A, CsrAux* aux, const float* d_x, float* d_y,
                             hipStream_t s);
 hipError_t launch_ell(const ELLMatrix* A, const float* d_x, float* d_y, hipStream_t s);

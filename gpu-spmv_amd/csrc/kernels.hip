@@ -57,6 +57,47 @@ void csr_vector_kernel(int num_rows, long long nnz,
     }
 }
 
+// VECTOR_CSR with the whole of x resident in LDS (use_texture on matrices with at most
+// 32 K columns): every workgroup (1024 threads, one per CU) copies x into LDS once and then
+// walks its rows as csr_vector_kernel does, gathering from LDS (~7 lanes/clk/CU) instead of
+// through the vector-memory path (<= 0.3 lane/clk/CU).
+template <int LANES>
+__global__ __launch_bounds__(1024)
+void csr_vector_ldsx_kernel(int num_rows, int num_cols, long long nnz,
+                            const int* __restrict__ row_ptrs,
+                            const int* __restrict__ cols,
+                            const float* __restrict__ vals,
+                            const float* __restrict__ x,
+                            float* __restrict__ y) {
+    extern __shared__ float xs[];
+    if ((reinterpret_cast<unsigned long long>(x) & 15) == 0) {
+        for (int i = threadIdx.x * 4; i < num_cols; i += 1024 * 4) {
+            if (i + 3 < num_cols) {
+                *reinterpret_cast<f32x4*>(xs + i) = *reinterpret_cast<const f32x4*>(x + i);
+            } else {
+                for (int k = i; k < num_cols; ++k) xs[k] = x[k];
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < num_cols; i += 1024) xs[i] = x[i];
+    }
+    __syncthreads();
+
+    constexpr int kRowsPerBlock = 1024 / LANES;
+    const int lane = threadIdx.x % LANES;
+    const int slot = threadIdx.x / LANES;
+    for (long long first = static_cast<long long>(blockIdx.x) * kRowsPerBlock; first < num_rows;
+         first += static_cast<long long>(gridDim.x) * kRowsPerBlock) {
+        const long long row = first + slot;
+        float acc = 0.0f;
+        if (row < num_rows) {
+            acc = row_partial_dot<LANES>(row_ptrs[row], row_ptrs[row + 1], lane, nnz, cols, vals, xs);
+        }
+        acc = group_sum<LANES>(acc);
+        if (lane == 0 && row < num_rows) y[row] = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // SCALAR_CSR ("stream"): the workgroup streams its rows' entries with
 // coalesced loads, parks the rounded products in LDS, then one thread per row
@@ -424,7 +465,44 @@ hipError_t launch_vector(const CSRMatrix* A, const float* d_x, float* d_y, hipSt
     return hipGetLastError();
 }
 
+template <int LANES>
+hipError_t launch_vector_ldsx(const CSRMatrix* A, const float* d_x, float* d_y, int grid, hipStream_t s) {
+    const size_t lds = (static_cast<size_t>(A->num_cols) * sizeof(float) + 15) & ~size_t(15);
+    static bool raised = false;       // > 64 KiB of dynamic LDS needs the limit raised once per kernel
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_vector_ldsx_kernel<LANES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    csr_vector_ldsx_kernel<LANES><<<grid, 1024, lds, s>>>(A->num_rows, A->num_cols, A->nnz, A->d_row_ptrs,
+                                                          A->d_col_indices, A->d_values, d_x, d_y);
+    return hipGetLastError();
+}
+
 } // namespace
+
+// x fits one CU's LDS and there are enough entries that 64+ workgroups each copying x is
+// noise next to the matrix stream: returns the grid to use, or 0 when not worthwhile.
+int vector_ldsx_grid(const CSRMatrix* A) {
+    if (A->num_cols <= 0 || A->num_cols > 32768 || A->num_rows < 4096) return 0;
+    const long long matrix_bytes = static_cast<long long>(A->nnz) * 8;
+    const long long x_bytes = static_cast<long long>(A->num_cols) * 4;
+    const long long grid = std::min<long long>(256, matrix_bytes / (8 * x_bytes));
+    return grid >= 64 ? static_cast<int>(grid) : 0;
+}
+
+hipError_t launch_csr_vector_ldsx(const CSRMatrix* A, const float* d_x, float* d_y, int lanes, int grid,
+                                  hipStream_t s) {
+    switch (lanes) {
+        case 1:  return launch_vector_ldsx<1>(A, d_x, d_y, grid, s);
+        case 2:  return launch_vector_ldsx<2>(A, d_x, d_y, grid, s);
+        case 4:  return launch_vector_ldsx<4>(A, d_x, d_y, grid, s);
+        case 8:  return launch_vector_ldsx<8>(A, d_x, d_y, grid, s);
+        case 16: return launch_vector_ldsx<16>(A, d_x, d_y, grid, s);
+        case 32: return launch_vector_ldsx<32>(A, d_x, d_y, grid, s);
+        default: return launch_vector_ldsx<64>(A, d_x, d_y, grid, s);
+    }
+}
 
 int pick_lanes_per_row(float avg) {
     // each lane takes four entries per step: aim for one step per row

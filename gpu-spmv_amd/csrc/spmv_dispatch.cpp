@@ -75,6 +75,11 @@ hipError_t enqueue_csr(const CSRMatrix* A, const float* d_x, float* d_y,
     switch (config->kernel_type) {
         case SpMVConfig::VECTOR_CSR: {
             const float avg = static_cast<float>(A->nnz) / A->num_rows;
+            if (config->use_texture) {          // small x: keep all of it in every CU's LDS
+                if (const int grid = vector_ldsx_grid(A)) {
+                    return launch_csr_vector_ldsx(A, d_x, d_y, pick_lanes_per_row(avg), grid, stream);
+                }
+            }
             return launch_csr_vector(A, d_x, d_y, pick_lanes_per_row(avg), stream);
         }
         case SpMVConfig::MERGE_PATH: {

@@ -411,3 +411,22 @@ def test_config3_full_size_ell(gpu, oracle):
     scale = np.abs(evals.reshape(k, n).astype(np.float64) * x[ecols.reshape(k, n)]).sum(axis=0)
     assert np.max(np.abs(got - want) / np.maximum(np.maximum(np.abs(want), scale), 1e-30)) <= REORDER_TOL
     E.close()
+
+
+@pytest.mark.parametrize("rows,cols,k", [(200_000, 30_000, 12), (65_536, 32_768, 40), (50_000, 1_003, 7)])
+def test_vector_kernel_with_x_resident_in_lds(gpu, oracle, rows, cols, k):
+    """use_texture on a matrix whose x fits one CU's LDS (<= 32 K columns): the vector kernel
+    gathers from an LDS copy of x; also with an x pointer that is only 4-byte aligned."""
+    rp, ci, va = gpu.synth.uniform_csr(9, 0, rows, cols, k)
+    x = gpu.synth.vector(9, 2, cols)
+    want = oracle.spmv_csr(rp, ci, va, x)
+    A = gpu.csr_from_arrays(rows, cols, rp, ci, va)
+    gpu.csr_to_gpu(A)
+    d_x, d_y = gpu.CudaBuffer(cols + 4), gpu.CudaBuffer(rows)
+    cfg = gpu.SpMVConfig(kernel_type=1, use_texture=True)
+    for offset in (0, 1):
+        d_x.copyFromHost(np.concatenate([np.zeros(offset, np.float32), x]), cols + offset)
+        assert gpu.spmv_csr(A, d_x.get() + 4 * offset, d_y, cfg, cols).error_code == 0
+        assert reorder_err(rp, ci, va, x, want, d_y.copyToHost(rows)) <= REORDER_TOL
+    assert not gpu.csr_has_tiled_plan(A)
+    gpu.csr_destroy(A)

@@ -36,6 +36,8 @@ def main():
     if "c4" in which:
         A = wl.power_law_csr_device(42, 1_000_000, 1_000_000)
         print("c4 nnz", A.nnz, flush=True); report("c4 1M power-law", A, kernels=(1, 2, 12)); A.close()
+    if "smallx" in which:     # x (30 K columns) fits one CU's LDS: direct gather vs x resident in LDS
+        A = wl.uniform_csr_device(42, 2_000_000, 30_000, 16); report("2M x 30K cols, 16/row", A, kernels=(1, 11)); A.close()
     if "shard8" in which:     # what one rank of 8 sees of C5: 1.25 M rows x 10 M columns
         A = wl.uniform_csr_device(42, 1_250_000, 10_000_000, 16); report("c5 shard 1/8", A, kernels=(11, 1)); A.close()
     if "shard2" in which:

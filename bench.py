@@ -118,6 +118,32 @@ def main():
 
     damping, never = 0.85, 0.0          # tolerance 0: the loop never converges, every step does full work
 
+    # ---- N > 1: how the new slices travel.  "push" = the step kernels store them straight into the
+    # peers' vectors (IPC-mapped, xGMI point-to-point) + a 16-byte all-reduce; "gather" = one RCCL
+    # all-gather per step.  Push is used only if every rank could map every peer AND a 4-step trial
+    # reproduces the gather path's vector on every rank; otherwise the run falls back to gather.
+    exchange = "none"
+    if world > 1:
+        exchange = "gather"
+        want = os.environ.get("SPMV_PR_EXCHANGE", "auto")
+        if want in ("auto", "push") and pr.enable_push():
+            def trial(mode):
+                pr.mode = mode
+                pr.reset()
+                for i in range(4):
+                    pr.iterate(i, damping, never)
+                torch.cuda.synchronize()
+                return pr.r[0][pr._pos].clone()
+            ref, got = trial("gather"), trial("push")
+            same = torch.allclose(got, ref, rtol=1e-5, atol=1e-12)
+            flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            pr.mode = "push" if int(flag.item()) == 1 else "gather"
+            exchange = pr.mode if pr.mode == "push" else "gather (push trial disagreed)"
+        elif want in ("auto", "push"):
+            exchange = "gather (peer mapping unavailable: %s)" % getattr(pr, "_push_error", "a peer failed")
+        pr.reset()
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -181,7 +207,11 @@ def main():
                    "nnz": nnz_total, "avg_nnz_per_row": k,
                    "kernel": "VECTOR_CSR with x staged through LDS tiles (fused PageRank step)" if tiled
                              else "VECTOR_CSR direct gather (fused PageRank step)",
-                   "parallelism": "row-shard x%d%s" % (world, "" if world == 1 else " + one RCCL all-gather per step (%d f32/rank, partial sums in the slice tails)" % layout.stride)},
+                   "parallelism": "row-shard x%d%s" % (world, "" if world == 1 else (
+                       " + slices pushed into the peers' vectors by the step kernels (xGMI stores) + RCCL all-reduce of 16 B per step"
+                       if exchange == "push" else
+                       " + one RCCL all-gather per step (%d f32/rank, partial sums in the slice tails)" % layout.stride)),
+                   "exchange": exchange},
         "gflops": round(2.0 * nnz_total * args.steps / elapsed / 1e9, 1),
         "pagerank_iters_per_sec": round(args.steps / elapsed, 2),
         "frac_of_hbm_peak_whole_job": round(value / (HBM_PEAK_GBS * world), 4),

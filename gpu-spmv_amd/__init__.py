@@ -137,6 +137,7 @@ _SIGNATURES = {
     "spmv_c_device_count": (c_int, []),
     "spmv_c_device_name": (c_int, [c_char_p, c_size_t]),
     "spmv_c_set_device": (c_int, [c_int]),
+    "spmv_c_enable_peer_access": (c_int, [c_int]),
     "spmv_c_set_stream": (None, [c_void_p]),
     "spmv_c_device_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
     "spmv_c_device_free": (c_int, [c_void_p]),
@@ -192,6 +193,7 @@ _SIGNATURES = {
     "spmv_c_pr_shard_destroy": (None, [c_void_p]),
     "spmv_c_pr_reset": (c_int, [c_void_p, c_float, c_void_p]),
     "spmv_c_pr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
+    "spmv_c_pr_step_push": (c_int, [c_void_p, c_void_p, c_void_p, c_float, POINTER(c_void_p), c_int, c_void_p]),
     "spmv_c_pr_reduce": (c_int, [c_void_p, c_void_p, c_void_p]),
     "spmv_c_pr_commit": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
     "spmv_c_pr_commit_gathered": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_float, c_void_p]),

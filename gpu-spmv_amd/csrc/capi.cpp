@@ -85,6 +85,23 @@ int spmv_c_device_name(char* buf, size_t buf_len) {
 
 int spmv_c_set_device(int ordinal) { return launch_code(hipSetDevice(ordinal)); }
 
+int spmv_c_enable_peer_access(int peer_ordinal) {
+    int current = 0;
+    if (hipGetDevice(&current) != hipSuccess) return kLaunch;
+    if (current == peer_ordinal) return 0;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, current, peer_ordinal) != hipSuccess || !can) {
+        (void)hipGetLastError();
+        return kInvalidArgument;
+    }
+    const hipError_t e = hipDeviceEnablePeerAccess(peer_ordinal, 0);
+    if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return kLaunch;
+}
+
 void spmv_c_set_stream(void* hip_stream) { spmv_set_stream(as_stream(hip_stream)); }
 
 int spmv_c_device_malloc(void** d_ptr, size_t bytes) {
@@ -338,7 +355,22 @@ int spmv_c_pr_reset(spmv_c_pr_shard* h, float dangling_sum, void* hip_stream) {
 int spmv_c_pr_step(spmv_c_pr_shard* h, const float* d_r_old, float* d_r_new, float damping,
                    void* hip_stream) {
     if (!h || !d_r_old || !d_r_new) return kInvalidArgument;
-    return launch_code(detail::pr_step(h->shard, d_r_old, d_r_new, damping, as_stream(hip_stream)));
+    return launch_code(detail::pr_step(h->shard, d_r_old, d_r_new, damping, detail::PushTargets{},
+                                       as_stream(hip_stream)));
+}
+
+int spmv_c_pr_step_push(spmv_c_pr_shard* h, const float* d_r_old, float* d_r_new, float damping,
+                        float* const* peer_r_new, int num_peers, void* hip_stream) {
+    if (!h || !d_r_old || !d_r_new || num_peers < 0 || num_peers > detail::kMaxPushPeers ||
+        (num_peers > 0 && !peer_r_new)) {
+        return kInvalidArgument;
+    }
+    detail::PushTargets push;
+    for (int p = 0; p < num_peers; ++p) {
+        if (!peer_r_new[p]) return kInvalidArgument;
+        push.ptr[push.count++] = peer_r_new[p];
+    }
+    return launch_code(detail::pr_step(h->shard, d_r_old, d_r_new, damping, push, as_stream(hip_stream)));
 }
 
 int spmv_c_pr_reduce(spmv_c_pr_shard* h, double* d_sums, void* hip_stream) {

@@ -48,7 +48,8 @@ void pr_step_kernel(int local_rows, int row_offset, int n_global, long long nnz,
                     const unsigned char* __restrict__ dangling, // full length mask
                     float damping,
                     const PrState* __restrict__ state,
-                    double* __restrict__ block_partials) {      // [2 * gridDim.x]
+                    double* __restrict__ block_partials,        // [2 * gridDim.x]
+                    PushTargets push) {                         // peers' vectors that also get the new slice
     if (state->done) return;
 
     constexpr int kRowsPerBlock = kBlock / LANES;
@@ -73,6 +74,7 @@ void pr_step_kernel(int local_rows, int row_offset, int n_global, long long nnz,
             const long long node = row_offset + row;
             const float fresh = __fadd_rn(__fadd_rn(__fmul_rn(damping, acc), dangling_term), teleport);
             r_new[node] = fresh;
+            for (int p = 0; p < push.count; ++p) push.ptr[p][node] = fresh;
             const float diff = __fsub_rn(fresh, r_old[node]);
             res2 += static_cast<double>(__fmul_rn(diff, diff));
             if (dangling[node]) mass += static_cast<double>(fresh);
@@ -182,10 +184,10 @@ int grid_for(long long rows, int rows_per_block) {
 
 template <int LANES>
 hipError_t launch_step(const PrShard& sh, const float* r_old, float* r_new, float damping,
-                       hipStream_t s) {
+                       const PushTargets& push, hipStream_t s) {
     pr_step_kernel<LANES><<<sh.grid, kBlock, 0, s>>>(
         sh.local_rows, sh.row_offset, sh.n_global, sh.nnz, sh.d_row_ptrs, sh.d_cols, sh.d_vals,
-        r_old, r_new, sh.d_dangling, damping, sh.d_state, sh.d_block_partials);
+        r_old, r_new, sh.d_dangling, damping, sh.d_state, sh.d_block_partials, push);
     return hipGetLastError();
 }
 
@@ -202,20 +204,20 @@ int pr_shard_prepare(PrShard* sh, const TiledPlan* tiled) {
 }
 
 hipError_t pr_step(const PrShard& sh, const float* r_old, float* r_new, float damping,
-                   hipStream_t s) {
+                   const PushTargets& push, hipStream_t s) {
     if (sh.local_rows <= 0) return hipSuccess;
     if (sh.tiled) {
         return tiled_pagerank_step(*sh.tiled, sh.row_offset, sh.n_global, r_old, r_new, sh.d_dangling,
-                                   damping, sh.d_state, sh.d_block_partials, s);
+                                   damping, sh.d_state, sh.d_block_partials, push, s);
     }
     switch (sh.lanes) {
-        case 1:  return launch_step<1>(sh, r_old, r_new, damping, s);
-        case 2:  return launch_step<2>(sh, r_old, r_new, damping, s);
-        case 4:  return launch_step<4>(sh, r_old, r_new, damping, s);
-        case 8:  return launch_step<8>(sh, r_old, r_new, damping, s);
-        case 16: return launch_step<16>(sh, r_old, r_new, damping, s);
-        case 32: return launch_step<32>(sh, r_old, r_new, damping, s);
-        default: return launch_step<64>(sh, r_old, r_new, damping, s);
+        case 1:  return launch_step<1>(sh, r_old, r_new, damping, push, s);
+        case 2:  return launch_step<2>(sh, r_old, r_new, damping, push, s);
+        case 4:  return launch_step<4>(sh, r_old, r_new, damping, push, s);
+        case 8:  return launch_step<8>(sh, r_old, r_new, damping, push, s);
+        case 16: return launch_step<16>(sh, r_old, r_new, damping, push, s);
+        case 32: return launch_step<32>(sh, r_old, r_new, damping, push, s);
+        default: return launch_step<64>(sh, r_old, r_new, damping, push, s);
     }
 }
 
@@ -384,7 +386,7 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     for (int iter = 0; ok && iter < config->max_iterations; ++iter) {
         const float* r_old = bufs[iter & 1];
         float* r_new = bufs[(iter + 1) & 1];
-        ok = detail::pr_step(shard, r_old, r_new, config->damping_factor, stream) == hipSuccess
+        ok = detail::pr_step(shard, r_old, r_new, config->damping_factor, detail::PushTargets{}, stream) == hipSuccess
           && detail::pr_reduce(shard, sums.ptr, stream) == hipSuccess
           && detail::pr_commit(shard, sums.ptr, config->tolerance, stream) == hipSuccess
           && hipMemcpyAsync(&pinned[iter & 1], state.ptr, sizeof(PrState),

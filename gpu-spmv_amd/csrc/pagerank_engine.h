@@ -18,6 +18,14 @@ struct PrState {
     int   reserved;
 };
 
+// Peers' rank vectors (IPC-mapped device pointers) that a step also writes its new slice
+// into, so that no all-gather is needed afterwards.  Passed to the kernels by value.
+constexpr int kMaxPushPeers = 15;
+struct PushTargets {
+    float* ptr[kMaxPushPeers];
+    int count = 0;
+};
+
 // One rank's slice of the problem: rows [row_offset, row_offset + local_rows)
 // of the n_global x n_global matrix, CSR with row_ptrs rebased to 0.
 struct PrShard {
@@ -41,7 +49,7 @@ int pr_max_blocks();
 // Returns the number of block-partial pairs the shard needs (size of d_block_partials / 2).
 int pr_shard_prepare(PrShard* shard, const TiledPlan* tiled);
 hipError_t pr_step(const PrShard& shard, const float* d_r_old, float* d_r_new, float damping,
-                   hipStream_t s);
+                   const PushTargets& push, hipStream_t s);
 hipError_t pr_reduce(const PrShard& shard, double* d_sums /*[2]*/, hipStream_t s);
 hipError_t pr_commit(const PrShard& shard, const double* d_sums, float tolerance, hipStream_t s);
 hipError_t pr_commit_gathered(const PrShard& shard, const float* d_gathered, int world, long long stride,

@@ -12,6 +12,7 @@ namespace spmv {
 namespace detail {
 
 struct PrState;
+struct PushTargets;
 
 // Per-matrix bucketed copy of the entries (built once on the device, cached in the
 // side table, dropped by csr_free_gpu).
@@ -65,7 +66,8 @@ hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipSt
 hipError_t tiled_pagerank_step(const TiledPlan& plan, int row_offset, int n_global,
                                const float* d_r_old, float* d_r_new,
                                const unsigned char* d_dangling, float damping,
-                               const PrState* d_state, double* d_block_partials, hipStream_t s);
+                               const PrState* d_state, double* d_block_partials,
+                               const PushTargets& push, hipStream_t s);
 
 } // namespace detail
 } // namespace spmv

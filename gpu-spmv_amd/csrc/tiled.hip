@@ -349,7 +349,7 @@ void tiled_pagerank_reduce_kernel(const int2* __restrict__ cells_t, int num_stri
                                   const float* __restrict__ r_old, float* __restrict__ r_new,
                                   const unsigned char* __restrict__ dangling, float damping,
                                   const PrState* __restrict__ state,
-                                  double* __restrict__ block_partials) {
+                                  double* __restrict__ block_partials, PushTargets push) {
     if (state->done) return;
     __shared__ float tile[R];
     tile_accumulate<R, kReduceBlock, U>(tile, blockIdx.x, num_strips, local_rows, cells_t, prod, a_lrow, seed);
@@ -363,6 +363,7 @@ void tiled_pagerank_reduce_kernel(const int2* __restrict__ cells_t, int num_stri
         const long long node = row_offset + first + i;
         const float fresh = __fadd_rn(__fadd_rn(__fmul_rn(damping, tile[i]), dangling_term), teleport);
         r_new[node] = fresh;
+        for (int p = 0; p < push.count; ++p) push.ptr[p][node] = fresh;     // straight into the peers' vectors
         const float diff = __fsub_rn(fresh, r_old[node]);
         res2 += static_cast<double>(__fmul_rn(diff, diff));
         if (dangling[node]) mass += static_cast<double>(fresh);
@@ -475,24 +476,27 @@ hipError_t launch_reduce(const TiledPlan& plan, float* d_y, hipStream_t s) {
 template <int R, int U>
 hipError_t launch_pagerank_reduce_as(const TiledPlan& plan, int row_offset, int n_global, const float* d_r_old,
                                      float* d_r_new, const unsigned char* d_dangling, float damping,
-                                     const PrState* d_state, double* d_block_partials, hipStream_t s) {
+                                     const PrState* d_state, double* d_block_partials,
+                                     const PushTargets& push, hipStream_t s) {
     tiled_pagerank_reduce_kernel<R, 512, U><<<plan.num_tiles, 512, 0, s>>>(
         reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_lrow, plan.seed,
-        plan.num_rows, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state, d_block_partials);
+        plan.num_rows, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state, d_block_partials,
+        push);
     return hipGetLastError();
 }
 
 template <int R>
 hipError_t launch_pagerank_reduce(const TiledPlan& plan, int row_offset, int n_global, const float* d_r_old,
                                   float* d_r_new, const unsigned char* d_dangling, float damping,
-                                  const PrState* d_state, double* d_block_partials, hipStream_t s) {
+                                  const PrState* d_state, double* d_block_partials,
+                                  const PushTargets& push, hipStream_t s) {
     switch (plan.run_chunks) {
         case 1:  return launch_pagerank_reduce_as<R, 1>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                        damping, d_state, d_block_partials, s);
+                                                        damping, d_state, d_block_partials, push, s);
         case 2:  return launch_pagerank_reduce_as<R, 2>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                        damping, d_state, d_block_partials, s);
+                                                        damping, d_state, d_block_partials, push, s);
         default: return launch_pagerank_reduce_as<R, 4>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                        damping, d_state, d_block_partials, s);
+                                                        damping, d_state, d_block_partials, push, s);
     }
 }
 
@@ -748,20 +752,21 @@ hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipSt
 hipError_t tiled_pagerank_step(const TiledPlan& plan, int row_offset, int n_global,
                                const float* d_r_old, float* d_r_new,
                                const unsigned char* d_dangling, float damping,
-                               const PrState* d_state, double* d_block_partials, hipStream_t s) {
+                               const PrState* d_state, double* d_block_partials,
+                               const PushTargets& push, hipStream_t s) {
     // After convergence the reduce kernel returns before touching r_new; the other kernels
     // then only rewrite scratch (product stream, seed vector), which nothing reads.
     const hipError_t e = launch_expand(plan, d_r_old, s);   // phase 1 + the long rows
     if (e != hipSuccess) return e;
     switch (plan.tile_rows) {
         case 1024: return launch_pagerank_reduce<1024>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                       damping, d_state, d_block_partials, s);
+                                                       damping, d_state, d_block_partials, push, s);
         case 2048: return launch_pagerank_reduce<2048>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                       damping, d_state, d_block_partials, s);
+                                                       damping, d_state, d_block_partials, push, s);
         case 4096: return launch_pagerank_reduce<4096>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                       damping, d_state, d_block_partials, s);
+                                                       damping, d_state, d_block_partials, push, s);
         default:   return launch_pagerank_reduce<8192>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                       damping, d_state, d_block_partials, s);
+                                                       damping, d_state, d_block_partials, push, s);
     }
 }
 

@@ -21,6 +21,13 @@ with stride = shard_len + 4; the shard's column indices are remapped to that lay
 (`Layout.remap_columns`), which costs nothing per iteration.  With world == 1 there is no
 padding, no collective, and commit() consumes the local sums directly.
 
+Optional "push" mode (enable_push): the step kernels store every new value straight into the
+peers' vectors as well (IPC-mapped buffers; xGMI is point-to-point, so all 7 links carry
+traffic at once, under the step's own epilogue).  What remains per iteration is a 16-byte
+all-reduce of the partial sums, which doubles as the cross-GPU barrier: it cannot complete
+on any rank before every rank's step kernels have finished, i.e. before every push has landed
+and before every peer has finished reading the buffer the next step will overwrite.
+
 Nothing else crosses ranks; the SpMV itself needs no collective (replicated x, sharded A).
 The compute engine is the C ABI of libspmv_amd.so (HipEngine); the loop itself is
 backend-agnostic so the world_size-2 gloo tests drive it with a test double on CPU tensors.
@@ -140,12 +147,18 @@ class HipEngine:
     def reset(self, dangling_sum: float) -> None:
         self._check(lib().spmv_c_pr_reset(self._shard, dangling_sum, self._stream()), "pr_reset")
 
-    def step(self, r_old: torch.Tensor, r_new: torch.Tensor, damping: float, sums_out: torch.Tensor = None):
+    def step(self, r_old: torch.Tensor, r_new: torch.Tensor, damping: float, sums_out: torch.Tensor = None,
+             push_to=None):
         """Enqueue one step; the two partial sums land in `sums_out` (2 doubles: a view into the
-        tail of this rank's slice when world > 1) or in the engine's own buffer."""
+        tail of this rank's slice when world > 1) or in the engine's own buffer.  `push_to`: ctypes
+        array of the peers' r_new device pointers — the step also stores its new slice there."""
         target = self._sums if sums_out is None else sums_out
-        self._check(lib().spmv_c_pr_step(self._shard, c_void_p(r_old.data_ptr()), c_void_p(r_new.data_ptr()),
-                                         damping, self._stream()), "pr_step")
+        if push_to is None:
+            self._check(lib().spmv_c_pr_step(self._shard, c_void_p(r_old.data_ptr()), c_void_p(r_new.data_ptr()),
+                                             damping, self._stream()), "pr_step")
+        else:
+            self._check(lib().spmv_c_pr_step_push(self._shard, c_void_p(r_old.data_ptr()), c_void_p(r_new.data_ptr()),
+                                                  damping, push_to, len(push_to), self._stream()), "pr_step_push")
         self._check(lib().spmv_c_pr_reduce(self._shard, c_void_p(target.data_ptr()), self._stream()), "pr_reduce")
         return target
 
@@ -184,6 +197,9 @@ class ShardedPageRank:
         self.r = [torch.zeros(layout.padded, dtype=torch.float32, device=self.device) for _ in range(2)]
         self._pos = torch.from_numpy(layout.positions()).to(self.device)
         self.num_dangling = None
+        self.mode = "gather"
+        self._peer_ptrs = None
+        self._peer_keepalive = []
 
     def _my_slice(self, buf):
         lay = self.layout
@@ -203,6 +219,49 @@ class ShardedPageRank:
         self.engine.set_dangling_mask(mask)
         return self
 
+    # -- optional: map the peers' vectors for the push-style exchange -------------------
+    def enable_push(self) -> bool:
+        """Exchange IPC handles of both rank vectors and map every peer's pair.  Returns True when
+        all ranks succeeded (then mode == "push"); on any failure every rank stays in gather mode."""
+        if self.world == 1:
+            return False
+        ok = 1
+        ptrs = None
+        try:
+            from torch.multiprocessing.reductions import reduce_tensor
+            mine = [reduce_tensor(buf) for buf in self.r]             # (rebuild_fn, args) per buffer
+            everyone = [None] * self.world
+            dist.all_gather_object(everyone, mine, group=self.group)
+            ptrs = [(c_void_p * (self.world - 1))() for _ in range(2)]
+            for which in range(2):
+                slot = 0
+                for p in range(self.world):
+                    if p == self.rank:
+                        continue
+                    fn, args = everyone[p][which]
+                    peer = fn(*args)                                   # CUDA tensor over the peer's memory
+                    assert peer.numel() == self.layout.padded and peer.dtype == torch.float32
+                    if peer.device != self.device:                     # another GPU of the node: peer access
+                        status = lib().spmv_c_enable_peer_access(peer.device.index)
+                        if status != 0:
+                            raise RuntimeError("peer access %s -> %s refused" % (self.device, peer.device))
+                    self._peer_keepalive.append(peer)
+                    ptrs[which][slot] = peer.data_ptr()
+                    slot += 1
+        except Exception as exc:                                        # noqa: BLE001 - any failure => gather mode
+            ok = 0
+            self._push_error = repr(exc)
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 1:
+            self._peer_ptrs = ptrs
+            self.mode = "push"
+            return True
+        self._peer_ptrs = None
+        self._peer_keepalive = []
+        self.mode = "gather"
+        return False
+
     def reset(self):
         start = float(np.float32(1.0) / np.float32(self.n))
         for buf in self.r:
@@ -215,6 +274,11 @@ class ShardedPageRank:
         r_old, r_new = self.r[k & 1], self.r[(k + 1) & 1]
         if self.world == 1:
             sums = self.engine.step(r_old, r_new, damping)
+            self.engine.commit(sums, tolerance)
+            return
+        if self.mode == "push":
+            sums = self.engine.step(r_old, r_new, damping, push_to=self._peer_ptrs[(k + 1) & 1])
+            dist.all_reduce(sums, group=self.group)        # 16 bytes: the sums and the cross-GPU barrier
             self.engine.commit(sums, tolerance)
             return
         self.engine.step(r_old, r_new, damping, self._my_tail(r_new))

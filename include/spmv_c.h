@@ -122,6 +122,8 @@ const char* spmv_c_version(void);
 int spmv_c_device_count(void);                       /* 0 when no HIP device is visible */
 int spmv_c_device_name(char* buf, size_t buf_len);   /* gcnArchName of the current device */
 int spmv_c_set_device(int ordinal);
+/* lets kernels of the current device store into memory of `peer_ordinal` (xGMI / PCIe peer access) */
+int spmv_c_enable_peer_access(int peer_ordinal);
 /* stream used by the synchronous entry points of the calling thread (NULL = null stream) */
 void spmv_c_set_stream(void* hip_stream);
 
@@ -223,6 +225,11 @@ void spmv_c_pr_shard_destroy(spmv_c_pr_shard* shard);
 int spmv_c_pr_reset(spmv_c_pr_shard* shard, float dangling_sum, void* hip_stream);
 int spmv_c_pr_step(spmv_c_pr_shard* shard, const float* d_r_old, float* d_r_new, float damping,
                    void* hip_stream);
+/* the same step, additionally storing every new value at the same offset of `num_peers` other
+ * vectors (host array of device pointers: the peers' r_new buffers, IPC-mapped) — a push-style
+ * all-gather over xGMI fused into the step's epilogue */
+int spmv_c_pr_step_push(spmv_c_pr_shard* shard, const float* d_r_old, float* d_r_new, float damping,
+                        float* const* peer_r_new, int num_peers, void* hip_stream);
 int spmv_c_pr_reduce(spmv_c_pr_shard* shard, double* d_sums /*[2]*/, void* hip_stream);
 int spmv_c_pr_commit(spmv_c_pr_shard* shard, const double* d_sums, float tolerance, void* hip_stream);
 /* multi-rank commit without an all-reduce: rank p's two partial sums (as doubles) sit in the 16-byte

@@ -214,10 +214,32 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
+def _share_torchs_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (same soname,
+    libamdhip64.so.7, loaded by path); if libspmv_amd.so pulled in /opt/rocm's copy first, a later
+    `import torch` would bring up a second runtime that finds no GPU.  So when torch is installed,
+    its copy is loaded first (without importing torch) and libspmv_amd.so binds to it by soname —
+    the same pairing that results when torch happens to be imported first."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    candidate = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(candidate):
+        try:
+            ctypes.CDLL(candidate, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib() -> ctypes.CDLL:
     """The loaded libspmv_amd.so; raises LibraryNotBuilt when it is missing."""
     global _lib
     if _lib is None:
+        _share_torchs_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise LibraryNotBuilt(
                 f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "

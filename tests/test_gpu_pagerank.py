@@ -229,3 +229,51 @@ def test_config5_pagerank_full_size_invariants(gpu):
     nxt = 0.85 * y + 0.85 * dangling / n + 0.15 / n
     assert np.sqrt(np.sum((nxt - r.ranks) ** 2)) < 5e-6
     A.close()
+
+
+def test_push_exchange_two_shards_on_one_gpu(gpu, oracle):
+    """The push-style exchange (spmv_c_pr_step_push): each shard's step stores its new slice into
+    the other shard's vector as well; the host only sums the two partial pairs (the all-reduce).
+    Both vectors must stay identical and track the unsharded run.  (Across processes the peers'
+    pointers come from IPC handles — rehearsed by `SPMV_BENCH_BACKEND=gloo bench.py --gpus 2`.)"""
+    torch = pytest.importorskip("torch")
+    from ctypes import c_void_p
+    prd = importlib.import_module("gpu-spmv_amd.pagerank_dist")
+    n = 300_000                                   # large enough for the tiled engine on both shards
+    rp, ci, va = graph(gpu, n, 10, 12, dangling=(5,))
+    dev = torch.device("cuda:0")
+
+    def engine(lay):
+        b, e = lay.row_begin, lay.row_end
+        lrp = torch.from_numpy((rp[b:e + 1] - rp[b]).astype(np.int32)).to(dev)
+        lci = torch.from_numpy(lay.remap_columns(ci[rp[b]:rp[e]]).astype(np.int32)).to(dev)
+        return prd.HipEngine(lrp, lci, torch.from_numpy(va[rp[b]:rp[e]]).to(dev), lay)
+
+    whole_lay = prd.Layout(n)
+    whole = prd.ShardedPageRank(engine(whole_lay), whole_lay).prepare()
+    lays = [prd.Layout(n, 2, r) for r in range(2)]
+    shards = [prd.ShardedPageRank(engine(l), l) for l in lays]
+    sums = shards[0].engine.column_sums() + shards[1].engine.column_sums()
+    for sp in shards:
+        mask = torch.zeros(sp.layout.padded, dtype=torch.uint8, device=dev)
+        mask[sp._pos] = (sums[sp._pos] == 0).to(torch.uint8)
+        sp.num_dangling = int(mask.sum().item())
+        sp.engine.set_dangling_mask(mask)
+        sp.reset()
+    whole.reset()
+    for k in range(5):
+        whole.iterate(k, 0.85, 0.0)
+        partial = []
+        for me, other in ((0, 1), (1, 0)):
+            target = (c_void_p * 1)(shards[other].r[(k + 1) & 1].data_ptr())
+            partial.append(shards[me].engine.step(shards[me].r[k & 1], shards[me].r[(k + 1) & 1], 0.85,
+                                                  push_to=target).clone())
+        total = partial[0] + partial[1]
+        for sp in shards:
+            sp.engine.commit(total, 0.0)
+        a, b = shards[0].r[(k + 1) & 1][shards[0]._pos], shards[1].r[(k + 1) & 1][shards[1]._pos]
+        torch.testing.assert_close(a, b, rtol=0, atol=0)
+        torch.testing.assert_close(a, whole.r[(k + 1) & 1][whole._pos], rtol=2e-6, atol=0)
+    assert shards[0].engine.status()[0] == shards[1].engine.status()[0] == whole.engine.status()[0] == 5
+    for sp in shards + [whole]:
+        sp.engine.close()

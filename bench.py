@@ -126,7 +126,9 @@ def main():
     if world > 1:
         exchange = "gather"
         want = os.environ.get("SPMV_PR_EXCHANGE", "auto")
-        if want in ("auto", "push") and pr.enable_push():
+        # one node, rank r on device r (torch.distributed.run sets LOCAL_RANK = RANK here)
+        peer_devices = list(range(world)) if backend == "nccl" else None
+        if want in ("auto", "push") and pr.enable_push(peer_devices):
             def trial(mode):
                 pr.mode = mode
                 pr.reset()
@@ -235,6 +237,8 @@ def main():
     engine.close()
     if world > 1:
         dist.barrier()
+    pr.close()
+    if world > 1:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -144,6 +144,9 @@ _SIGNATURES = {
     "spmv_c_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
     "spmv_c_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
     "spmv_c_device_synchronize": (c_int, []),
+    "spmv_c_ipc_get_handle": (c_int, [c_void_p, c_char_p]),
+    "spmv_c_ipc_open_handle": (c_int, [c_char_p, POINTER(c_void_p)]),
+    "spmv_c_ipc_close": (c_int, [c_void_p]),
     "spmv_c_csr_create": (POINTER(CSRMatrix), [c_int, c_int, c_int]),
     "spmv_c_csr_destroy": (None, [POINTER(CSRMatrix)]),
     "spmv_c_csr_from_dense": (c_int, [POINTER(CSRMatrix), c_void_p, c_int, c_int]),

@@ -132,6 +132,37 @@ int spmv_c_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
 
 int spmv_c_device_synchronize(void) { return launch_code(hipDeviceSynchronize()); }
 
+static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+
+int spmv_c_ipc_get_handle(void* d_ptr, unsigned char handle_out[64]) {
+    if (!d_ptr || !handle_out) return kInvalidArgument;
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, d_ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return kLaunch;
+    }
+    std::memcpy(handle_out, &h, sizeof(h));
+    return 0;
+}
+
+int spmv_c_ipc_open_handle(const unsigned char handle[64], void** d_ptr_out) {
+    if (!handle || !d_ptr_out) return kInvalidArgument;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, sizeof(h));
+    *d_ptr_out = nullptr;
+    if (hipIpcOpenMemHandle(d_ptr_out, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+        (void)hipGetLastError();
+        *d_ptr_out = nullptr;
+        return kLaunch;
+    }
+    return 0;
+}
+
+int spmv_c_ipc_close(void* d_ptr) {
+    if (!d_ptr) return 0;
+    return launch_code(hipIpcCloseMemHandle(d_ptr));
+}
+
 // ---- CSR ----
 spmv_c_csr* spmv_c_csr_create(int rows, int cols, int nnz) {
     return reinterpret_cast<spmv_c_csr*>(csr_create(rows, cols, nnz));

@@ -194,12 +194,44 @@ class ShardedPageRank:
         self.engine, self.layout, self.group = engine, layout, group
         self.n, self.rank, self.world = layout.n, layout.rank, layout.world
         self.device = device if device is not None else getattr(engine, "device", torch.device("cpu"))
-        self.r = [torch.zeros(layout.padded, dtype=torch.float32, device=self.device) for _ in range(2)]
+        # The two rank vectors.  On a GPU they are plain hipMalloc allocations made through the C ABI
+        # (base pointers, so they can be exported with hipIpcGetMemHandle for the push exchange) and
+        # viewed by torch through __cuda_array_interface__; on CPU (gloo tests) ordinary tensors.
+        self._owned = []
+        if self.device.type == "cuda":
+            self.r = [self._device_vector(layout.padded) for _ in range(2)]
+        else:
+            self.r = [torch.zeros(layout.padded, dtype=torch.float32, device=self.device) for _ in range(2)]
         self._pos = torch.from_numpy(layout.positions()).to(self.device)
         self.num_dangling = None
         self.mode = "gather"
         self._peer_ptrs = None
         self._peer_keepalive = []
+
+    def _device_vector(self, count):
+        ptr = c_void_p(None)
+        status = lib().spmv_c_device_malloc(byref(ptr), max(count, 1) * 4)
+        if status != 0:
+            raise RuntimeError("device allocation of the rank vector failed")
+        self._owned.append(ptr)
+
+        class _Raw:                      # zero-copy view for torch
+            __cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr.value, False),
+                                        "version": 2, "strides": None}
+        t = torch.as_tensor(_Raw(), device=self.device)
+        t.zero_()
+        return t
+
+    def close(self):
+        """Unmap the peers' vectors and free the rank vectors (the engine is closed by its owner)."""
+        for p in self._peer_keepalive:
+            lib().spmv_c_ipc_close(c_void_p(p))
+        self._peer_keepalive = []
+        self._peer_ptrs = None
+        self.r = []
+        for ptr in self._owned:
+            lib().spmv_c_device_free(ptr)
+        self._owned = []
 
     def _my_slice(self, buf):
         lay = self.layout
@@ -220,33 +252,47 @@ class ShardedPageRank:
         return self
 
     # -- optional: map the peers' vectors for the push-style exchange -------------------
-    def enable_push(self) -> bool:
+    def enable_push(self, peer_devices=None) -> bool:
         """Exchange IPC handles of both rank vectors and map every peer's pair.  Returns True when
         all ranks succeeded (then mode == "push"); on any failure every rank stays in gather mode."""
         if self.world == 1:
             return False
+        import ctypes
         ok = 1
         ptrs = None
-        try:
-            from torch.multiprocessing.reductions import reduce_tensor
-            mine = [reduce_tensor(buf) for buf in self.r]             # (rebuild_fn, args) per buffer
-            everyone = [None] * self.world
-            dist.all_gather_object(everyone, mine, group=self.group)
+        mine = []
+        try:                                                            # local: export my two vectors
+            for ptr in self._owned[:2]:
+                raw = ctypes.create_string_buffer(64)
+                if lib().spmv_c_ipc_get_handle(ptr, raw) != 0:
+                    raise RuntimeError("hipIpcGetMemHandle refused")
+                mine.append(raw.raw)
+            if len(mine) != 2:
+                raise RuntimeError("rank vectors are not device allocations")
+        except Exception as exc:                                        # noqa: BLE001
+            ok = 0
+            self._push_error = repr(exc)
+        agreed = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=self.group)
+        if int(agreed.item()) == 0:                                     # every rank skips the exchange together
+            self.mode = "gather"
+            return False
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=self.group)
+        try:                                                            # local: map every peer's pair
             ptrs = [(c_void_p * (self.world - 1))() for _ in range(2)]
             for which in range(2):
                 slot = 0
                 for p in range(self.world):
                     if p == self.rank:
                         continue
-                    fn, args = everyone[p][which]
-                    peer = fn(*args)                                   # CUDA tensor over the peer's memory
-                    assert peer.numel() == self.layout.padded and peer.dtype == torch.float32
-                    if peer.device != self.device:                     # another GPU of the node: peer access
-                        status = lib().spmv_c_enable_peer_access(peer.device.index)
-                        if status != 0:
-                            raise RuntimeError("peer access %s -> %s refused" % (self.device, peer.device))
-                    self._peer_keepalive.append(peer)
-                    ptrs[which][slot] = peer.data_ptr()
+                    if peer_devices is not None and which == 0 and peer_devices[p] != peer_devices[self.rank]:
+                        lib().spmv_c_enable_peer_access(int(peer_devices[p]))   # best effort; the open below decides
+                    opened = c_void_p(None)
+                    if lib().spmv_c_ipc_open_handle(everyone[p][which], byref(opened)) != 0 or not opened.value:
+                        raise RuntimeError("hipIpcOpenMemHandle refused for rank %d" % p)
+                    self._peer_keepalive.append(opened.value)
+                    ptrs[which][slot] = opened.value
                     slot += 1
         except Exception as exc:                                        # noqa: BLE001 - any failure => gather mode
             ok = 0
@@ -257,6 +303,8 @@ class ShardedPageRank:
             self._peer_ptrs = ptrs
             self.mode = "push"
             return True
+        for p in self._peer_keepalive:
+            lib().spmv_c_ipc_close(c_void_p(p))
         self._peer_ptrs = None
         self._peer_keepalive = []
         self.mode = "gather"

@@ -133,6 +133,13 @@ int spmv_c_device_free(void* d_ptr);                             /* dtor / relea
 int spmv_c_memcpy_h2d(void* d_dst, const void* src, size_t bytes);   /* copyFromHost */
 int spmv_c_memcpy_d2h(void* dst, const void* d_src, size_t bytes);   /* copyToHost */
 int spmv_c_device_synchronize(void);
+/* extension: share a spmv_c_device_malloc'ed buffer with another process on the same node
+ * (hipIpcGetMemHandle / hipIpcOpenMemHandle); handles are 64 opaque bytes.  The opener maps the
+ * buffer for ITS current device, so its kernels may load/store it directly (over xGMI when the
+ * buffer lives on another GPU). */
+int spmv_c_ipc_get_handle(void* d_ptr, unsigned char handle_out[64]);
+int spmv_c_ipc_open_handle(const unsigned char handle[64], void** d_ptr_out);
+int spmv_c_ipc_close(void* d_ptr);
 
 /* ---- CSR container: reference include/spmv/csr_matrix.h:31-71 ---- */
 spmv_c_csr* spmv_c_csr_create(int rows, int cols, int nnz);

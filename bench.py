@@ -137,11 +137,13 @@ def main():
                 torch.cuda.synchronize()
                 return pr.r[0][pr._pos].clone()
             ref, got = trial("gather"), trial("push")
-            same = torch.allclose(got, ref, rtol=1e-5, atol=1e-12)
-            flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=device)
+            # two runs of the same path already differ in the last bits (the LDS adds of a row meet in
+            # scheduling order); a stale or missing slice would be off by orders of magnitude more
+            worst = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max())
+            flag = torch.tensor([1 if worst <= 1e-4 else 0], dtype=torch.int32, device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             pr.mode = "push" if int(flag.item()) == 1 else "gather"
-            exchange = pr.mode if pr.mode == "push" else "gather (push trial disagreed)"
+            exchange = pr.mode if pr.mode == "push" else "gather (push trial disagreed: rel %.3g)" % worst
         elif want in ("auto", "push"):
             exchange = "gather (peer mapping unavailable: %s)" % getattr(pr, "_push_error", "a peer failed")
         pr.reset()

@@ -316,6 +316,12 @@ class ShardedPageRank:
             buf.zero_()
             buf[self._pos] = start
         self.engine.reset(initial_dangling_mass(self.num_dangling, self.n))
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            # peers may store into these vectors (push mode): nobody proceeds before every rank's
+            # vectors hold the start state
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)
 
     def iterate(self, k, damping, tolerance):
         """Enqueue iteration k (0-based): r[k & 1] -> r[(k + 1) & 1]."""

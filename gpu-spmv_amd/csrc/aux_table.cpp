@@ -60,8 +60,13 @@ void aux_drop(const void* key) {
     release(victim);
 }
 
+namespace {
+std::mutex g_build_lock;   // one plan build at a time (two threads may meet on the same matrix)
+}
+
 const TiledPlan* tiled_plan_for(const CSRMatrix* A, hipStream_t s) {
     if (!A || !A->d_row_ptrs || !tiled_eligible(A)) return nullptr;
+    std::lock_guard<std::mutex> building(g_build_lock);
     CsrAux* aux = aux_lookup(A->d_row_ptrs, true);
     if (aux->tiled && (aux->tiled->num_rows != A->num_rows || aux->tiled->num_cols != A->num_cols ||
                        aux->tiled->csr_nnz != A->nnz)) {
@@ -104,6 +109,7 @@ void ell_aux_drop(const void* key) {
 
 const TiledPlan* tiled_plan_for(const ELLMatrix* A, hipStream_t s) {
     if (!A || !A->d_col_indices || !A->d_values || !tiled_eligible(A)) return nullptr;
+    std::lock_guard<std::mutex> building(g_build_lock);
     EllAux* aux = ell_aux_lookup(A->d_col_indices, true);
     if (aux->tiled && (aux->tiled->num_rows != A->num_rows || aux->tiled->num_cols != A->num_cols)) {
         tiled_free(aux->tiled);

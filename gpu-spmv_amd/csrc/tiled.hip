@@ -511,7 +511,9 @@ bool eligible_dims(long long rows, long long cols, long long nnz) {
     }();
     static const long long min_cols = [] {
         const char* env = std::getenv("SPMV_TILED_MIN_COLS");
-        return env ? std::atoll(env) : 262144LL;      // below ~1 MB of x the direct gather (L2 hits) is as fast
+        // measured crossover (tools/quick_bench.py crossover, 1 M rows x 16): 65536 columns tie
+        // (69 vs 71 us), 131072 columns 60 vs 74 us, 262144 columns 57 vs 76 us
+        return env ? std::atoll(env) : 65536LL;
     }();
     if (!enabled || rows <= 0 || nnz < (1 << 20) || cols < min_cols) return false;
     int w = 0, r = 0;

@@ -6,10 +6,6 @@ import sys
 import numpy as np
 import pytest
 
-# The LDS-tiled engine engages from 2 M columns by default; the tests exercise it on smaller
-# (faster to check) matrices.  Read once when the library loads, so set it before that.
-os.environ.setdefault("SPMV_TILED_MIN_COLS", "262144")
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -36,6 +36,9 @@ def main():
     if "c4" in which:
         A = wl.power_law_csr_device(42, 1_000_000, 1_000_000)
         print("c4 nnz", A.nnz, flush=True); report("c4 1M power-law", A, kernels=(1, 2, 12)); A.close()
+    if "crossover" in which:  # where does the LDS-tiled engine start to beat the direct gather?
+        for cols in (65_536, 131_072, 262_144, 524_288):
+            A = wl.uniform_csr_device(42, 1_000_000, cols, 16); report("1M rows x %d cols" % cols, A, kernels=(1, 11)); A.close()
     if "smallx" in which:     # x (30 K columns) fits one CU's LDS: direct gather vs x resident in LDS
         A = wl.uniform_csr_device(42, 2_000_000, 30_000, 16); report("2M x 30K cols, 16/row", A, kernels=(1, 11)); A.close()
     if "shard8" in which:     # what one rank of 8 sees of C5: 1.25 M rows x 10 M columns

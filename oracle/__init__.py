@@ -65,6 +65,16 @@ def spmv_csr(row_ptrs, col_indices, values, x) -> np.ndarray:
     return y
 
 
+def spmv_csr_parallel(row_ptrs, col_indices, values, x, threads) -> np.ndarray:
+    """OpenMP static row blocks over `threads` host threads; bit-identical to spmv_csr."""
+    row_ptrs, col_indices, values, x = _i32(row_ptrs), _i32(col_indices), _f32(values), _f32(x)
+    rows = row_ptrs.size - 1
+    y = np.empty(rows, dtype=np.float32)
+    lib().oracle_spmv_csr_parallel(ctypes.c_int(rows), _p(row_ptrs), _p(col_indices), _p(values), _p(x), _p(y),
+                                   ctypes.c_int(int(threads)))
+    return y
+
+
 def spmv_ell(num_rows, max_nnz_per_row, col_indices, values, x) -> np.ndarray:
     col_indices, values, x = _i32(col_indices), _f32(values), _f32(x)
     y = np.empty(num_rows, dtype=np.float32)

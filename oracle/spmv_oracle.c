@@ -37,6 +37,21 @@ void oracle_spmv_csr(int num_rows, const int* row_ptrs, const int* col_indices,
     }
 }
 
+/* The same row loop with OpenMP static row blocks — the "all host cores" CPU baseline that
+ * BASELINE.md §4 asks for next to the single-thread one (the reference itself has no OpenMP).
+ * Per-row arithmetic is unchanged, so y is bit-identical to oracle_spmv_csr. */
+void oracle_spmv_csr_parallel(int num_rows, const int* row_ptrs, const int* col_indices,
+                              const float* values, const float* x, float* y, int threads) {
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (int i = 0; i < num_rows; i++) {
+        float sum = 0.0f;
+        for (int j = row_ptrs[i]; j < row_ptrs[i + 1]; j++) {
+            sum += values[j] * x[col_indices[j]];
+        }
+        y[i] = sum;
+    }
+}
+
 /* y = A x, column-major ELL, padding (col < 0) skipped — src/spmv_cpu.cpp:18-32 */
 void oracle_spmv_ell(int num_rows, int max_nnz_per_row, const int* col_indices,
                      const float* values, const float* x, float* y) {

@@ -223,3 +223,62 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "spmv_oracle" not in text and "liboracle" not in text, f
+
+
+def test_container_properties_random(spmv, tmp_path):
+    """Property loops of the reference's container tests on random dense matrices:
+    P1 dense->CSR->dense round trip (tests/test_csr.cpp:18-43), P2 csr_get_element (:47-76),
+    P3 CSR serialise round trip (:80-127), P4 ELL round trip, P5 padding = (-1, 0.0f)
+    (tests/test_ell.cpp:48-80), P6 ell_index == k*rows+row (:84-108), P7 ELL serialise,
+    ell_from_csr == ell_from_dense."""
+    rng = np.random.default_rng(42)
+    for it in range(40):
+        rows, cols = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+        dense = np.where(rng.random((rows, cols)) < rng.uniform(0.0, 0.5), rng.uniform(-10, 10, (rows, cols)), 0)
+        dense = dense.astype(np.float32)
+        A = spmv.csr_create(0, 0, 0)
+        assert spmv.csr_from_dense(A, dense, rows, cols) == 0
+        np.testing.assert_array_equal(spmv.csr_to_dense(A), dense)                                   # P1
+        for _ in range(10):                                                                          # P2
+            r, c = int(rng.integers(0, rows)), int(rng.integers(0, cols))
+            assert spmv.csr_get_element(A, r, c) == dense[r, c]
+        rp, ci, va = spmv.csr_host_arrays(A)
+        assert rp[0] == 0 and rp[-1] == A.contents.nnz == np.count_nonzero(dense)
+        assert all((np.diff(ci[rp[r]:rp[r + 1]]) > 0).all() for r in range(rows))                    # ascending columns
+        path = str(tmp_path / "m.csr")
+        assert spmv.csr_serialize(A, path) == 0                                                      # P3
+        B = spmv.csr_create(0, 0, 0)
+        assert spmv.csr_deserialize(B, path) == 0
+        np.testing.assert_array_equal(spmv.csr_to_dense(B), dense)
+
+        E = spmv.ell_create(0, 0, 0)
+        assert spmv.ell_from_dense(E, dense, rows, cols) == 0
+        np.testing.assert_array_equal(spmv.ell_to_dense(E), dense)                                   # P4
+        k = E.contents.max_nnz_per_row
+        assert k == int((dense != 0).sum(axis=1).max())
+        ecols, evals = spmv.ell_host_arrays(E)
+        if k:
+            pad = ecols < 0
+            assert (ecols[pad] == -1).all() and (evals[pad] == 0).all()                               # P5
+            grid = ecols.reshape(k, rows)
+            for r in range(rows):                                                                    # P6: column-major slots
+                want = np.flatnonzero(dense[r])
+                got = grid[:, r][grid[:, r] >= 0]
+                np.testing.assert_array_equal(got, want)
+                assert spmv.ell_index(r, k - 1, rows) == (k - 1) * rows + r
+        for _ in range(10):
+            r, c = int(rng.integers(0, rows)), int(rng.integers(0, cols))
+            assert spmv.ell_get_element(E, r, c) == dense[r, c]
+        E2 = spmv.ell_create(0, 0, 0)
+        assert spmv.ell_from_csr(E2, A) == 0
+        for a, b in zip(spmv.ell_host_arrays(E), spmv.ell_host_arrays(E2)):
+            np.testing.assert_array_equal(a, b)
+        epath = str(tmp_path / "m.ell")
+        assert spmv.ell_serialize(E, epath) == 0                                                     # P7
+        E3 = spmv.ell_create(0, 0, 0)
+        assert spmv.ell_deserialize(E3, epath) == 0
+        np.testing.assert_array_equal(spmv.ell_to_dense(E3), dense)
+        for h in (E, E2, E3):
+            spmv.ell_destroy(h)
+        spmv.csr_destroy(A)
+        spmv.csr_destroy(B)

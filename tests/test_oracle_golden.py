@@ -134,3 +134,12 @@ def test_oracle_matches_compiled_reference_live(oracle):
         rp, ci, va = oracle.csr_from_dense(dense)
         np.testing.assert_array_equal(rp, ref["csr_row_ptrs"])
         np.testing.assert_array_equal(oracle.spmv_csr(rp, ci, va, x).view(np.uint32), ref["y_csr"].view(np.uint32))
+
+
+def test_parallel_cpu_baseline_is_bit_identical(oracle, golden):
+    """The OpenMP row-block loop used for the all-cores CPU baseline computes the oracle's y exactly."""
+    data, names = golden
+    for n in names:
+        args = (data[f"{n}/csr_row_ptrs"], data[f"{n}/csr_col_indices"], data[f"{n}/csr_values"], data[f"{n}/x"])
+        np.testing.assert_array_equal(oracle.spmv_csr_parallel(*args, threads=3).view(np.uint32),
+                                      oracle.spmv_csr(*args).view(np.uint32), err_msg=n)

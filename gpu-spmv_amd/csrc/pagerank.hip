@@ -177,6 +177,48 @@ void pr_mask_kernel(const float* __restrict__ col_sums, int n, unsigned char* __
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
 }
 
+// ---- top-k by radix select on the float bit patterns (non-negative ranks order like uints) ----
+// pass A: histogram of the high 16 bits; pass B: histogram of the low 16 bits of the values
+// whose high half equals `prefix`; pass C: gather everything above the threshold plus as many
+// equal-to-threshold values as are still needed.
+__global__ __launch_bounds__(kBlock)
+void topk_hist_hi_kernel(const unsigned int* __restrict__ bits, size_t n, unsigned int* __restrict__ hist,
+                         unsigned int* __restrict__ bad) {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const unsigned int b = bits[i];
+        if (b > 0x7F800000u) atomicOr(bad, 1u);           // negative or NaN: not orderable this way
+        atomicAdd(&hist[b >> 16], 1u);
+    }
+}
+
+__global__ __launch_bounds__(kBlock)
+void topk_hist_lo_kernel(const unsigned int* __restrict__ bits, size_t n, unsigned int prefix,
+                         unsigned int* __restrict__ hist) {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const unsigned int b = bits[i];
+        if ((b >> 16) == prefix) atomicAdd(&hist[b & 0xFFFFu], 1u);
+    }
+}
+
+__global__ __launch_bounds__(kBlock)
+void topk_gather_kernel(const unsigned int* __restrict__ bits, size_t n, unsigned int threshold,
+                        unsigned int take_equal, unsigned int* __restrict__ cursor /*[2]: out, equal*/,
+                        TopKNode* __restrict__ out) {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const unsigned int b = bits[i];
+        bool keep = b > threshold;
+        if (b == threshold) keep = atomicAdd(&cursor[1], 1u) < take_equal;
+        if (keep) {
+            const unsigned int at = atomicAdd(&cursor[0], 1u);
+            out[at].node_id = static_cast<int>(i);
+            out[at].rank = __uint_as_float(b);
+        }
+    }
+}
+
 int grid_for(long long rows, int rows_per_block) {
     const long long blocks = (rows + rows_per_block - 1) / rows_per_block;
     return static_cast<int>(std::max(1LL, std::min<long long>(blocks, kMaxResidentBlocks)));
@@ -436,8 +478,84 @@ void pagerank_free(PageRankResult* result) {
     }
 }
 
+namespace {
+
+// Device selection for large vectors: uploads the ranks, finds the k-th
+// largest value by a two-level radix histogram, gathers the k winners and sorts only those on the
+// host.  Returns false (caller falls back to the host partial sort) on any failure or when the
+// ranks hold negative values / NaNs.
+bool top_k_on_device(const float* ranks, int n, int keep, TopKNode* top_k) {
+    using namespace detail;
+    hipStream_t s = current_stream();
+    DeviceArray<unsigned int> bits, hist, scratch;
+    DeviceArray<TopKNode> winners;
+    if (bits.alloc(n) != hipSuccess || hist.alloc(65536) != hipSuccess || scratch.alloc(4) != hipSuccess ||
+        winners.alloc(keep) != hipSuccess) {
+        return false;
+    }
+    std::vector<unsigned int> host_hist(65536);
+    unsigned int host_scratch[4] = {0, 0, 0, 0};
+    const int grid = 2048;
+    bool ok = hipMemcpyAsync(bits.ptr, ranks, static_cast<size_t>(n) * sizeof(float), hipMemcpyHostToDevice, s) == hipSuccess
+           && hipMemsetAsync(hist.ptr, 0, 65536 * sizeof(unsigned int), s) == hipSuccess
+           && hipMemsetAsync(scratch.ptr, 0, sizeof(host_scratch), s) == hipSuccess;
+    if (!ok) return false;
+    topk_hist_hi_kernel<<<grid, dev::kBlock, 0, s>>>(bits.ptr, n, hist.ptr, scratch.ptr + 2);
+    ok = hipMemcpyAsync(host_hist.data(), hist.ptr, 65536 * sizeof(unsigned int), hipMemcpyDeviceToHost, s) == hipSuccess
+      && hipMemcpyAsync(host_scratch, scratch.ptr, sizeof(host_scratch), hipMemcpyDeviceToHost, s) == hipSuccess
+      && hipStreamSynchronize(s) == hipSuccess;
+    if (!ok || host_scratch[2] != 0) return false;
+
+    // walk the histogram from the top: `prefix` is the bin holding the k-th largest value
+    unsigned long long above = 0;
+    int prefix = 65535;
+    for (; prefix >= 0; --prefix) {
+        if (above + host_hist[prefix] >= static_cast<unsigned long long>(keep)) break;
+        above += host_hist[prefix];
+    }
+    if (prefix < 0) return false;
+    ok = hipMemsetAsync(hist.ptr, 0, 65536 * sizeof(unsigned int), s) == hipSuccess;
+    topk_hist_lo_kernel<<<grid, dev::kBlock, 0, s>>>(bits.ptr, n, static_cast<unsigned int>(prefix), hist.ptr);
+    ok = ok && hipMemcpyAsync(host_hist.data(), hist.ptr, 65536 * sizeof(unsigned int), hipMemcpyDeviceToHost, s) == hipSuccess
+            && hipStreamSynchronize(s) == hipSuccess;
+    if (!ok) return false;
+    int low = 65535;
+    for (; low >= 0; --low) {
+        if (above + host_hist[low] >= static_cast<unsigned long long>(keep)) break;
+        above += host_hist[low];
+    }
+    if (low < 0) return false;
+    const unsigned int threshold = (static_cast<unsigned int>(prefix) << 16) | static_cast<unsigned int>(low);
+    const unsigned int take_equal = static_cast<unsigned int>(keep - above);   // ties: any of the equals
+    topk_gather_kernel<<<grid, dev::kBlock, 0, s>>>(bits.ptr, n, threshold, take_equal, scratch.ptr, winners.ptr);
+    std::vector<TopKNode> host_winners(keep);
+    ok = hipGetLastError() == hipSuccess
+      && hipMemcpyAsync(host_winners.data(), winners.ptr, static_cast<size_t>(keep) * sizeof(TopKNode),
+                        hipMemcpyDeviceToHost, s) == hipSuccess
+      && hipMemcpyAsync(host_scratch, scratch.ptr, sizeof(host_scratch), hipMemcpyDeviceToHost, s) == hipSuccess
+      && hipStreamSynchronize(s) == hipSuccess;
+    if (!ok || host_scratch[0] != static_cast<unsigned int>(keep)) return false;
+    std::sort(host_winners.begin(), host_winners.end(), [](const TopKNode& a, const TopKNode& b) {
+        return a.rank > b.rank || (a.rank == b.rank && a.node_id < b.node_id);
+    });
+    std::copy(host_winners.begin(), host_winners.end(), top_k);
+    return true;
+}
+
+} // namespace
+
 void pagerank_top_k(const PageRankResult* result, int num_nodes, int k, TopKNode* top_k) {
     if (!result || !result->ranks || !top_k || k <= 0 || num_nodes <= 0) return;
+
+    // large vectors, small k: select on the device (the host partial sort is O(n log k))
+    if (num_nodes >= (1 << 20) && k <= 65536) {
+        int devices = 0;
+        if (hipGetDeviceCount(&devices) == hipSuccess && devices > 0 &&
+            top_k_on_device(result->ranks, num_nodes, std::min(k, num_nodes), top_k)) {
+            return;
+        }
+        (void)hipGetLastError();
+    }
 
     std::vector<int> order(num_nodes);
     for (int i = 0; i < num_nodes; ++i) order[i] = i;

@@ -277,3 +277,25 @@ def test_push_exchange_two_shards_on_one_gpu(gpu, oracle):
     assert shards[0].engine.status()[0] == shards[1].engine.status()[0] == whole.engine.status()[0] == 5
     for sp in shards + [whole]:
         sp.engine.close()
+
+
+def test_top_k_on_the_device_for_large_vectors(gpu):
+    """for >= 2^20 nodes pagerank_top_k selects on the device (radix select on
+    the float bits); same answer as a full sort, descending, ties broken arbitrarily among equals."""
+    rng = np.random.default_rng(3)
+    n = 3_000_000
+    ranks = rng.random(n, dtype=np.float32)
+    ranks[rng.integers(0, n, 1000)] = np.float32(0.99999)            # a block of ties inside the top
+    ranks /= ranks.sum(dtype=np.float64)
+    result = gpu.PageRankResult(ranks.astype(np.float32), 1, 0.0, True)
+    for k in (1, 10, 777, 5000):
+        top = gpu.pagerank_top_k(result, n, k)
+        got = np.array([r for _, r in top], np.float32)
+        want = np.sort(result.ranks)[::-1][:k]
+        np.testing.assert_array_equal(got, want)                     # the k largest values, in order
+        ids = [i for i, _ in top]
+        assert len(set(ids)) == k and all(result.ranks[i] == r for i, r in top)
+    # negative values are not orderable by bit pattern: falls back to the host path, still right
+    result.ranks[5] = -1.0
+    top = gpu.pagerank_top_k(result, n, 3)
+    np.testing.assert_array_equal(np.array([r for _, r in top], np.float32), np.sort(result.ranks)[::-1][:3])

@@ -430,3 +430,46 @@ def test_vector_kernel_with_x_resident_in_lds(gpu, oracle, rows, cols, k):
         assert reorder_err(rp, ci, va, x, want, d_y.copyToHost(rows)) <= REORDER_TOL
     assert not gpu.csr_has_tiled_plan(A)
     gpu.csr_destroy(A)
+
+
+def _csr_from_lengths_and_cols(lens, col_fn, rng):
+    rp = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    row_of = np.repeat(np.arange(len(lens), dtype=np.int64), lens)
+    slot = np.arange(rp[-1], dtype=np.int64) - rp[row_of]
+    ci = col_fn(row_of, slot).astype(np.int32)
+    va = rng.uniform(-1, 1, ci.size).astype(np.float32)
+    return rp.astype(np.int32), ci, va
+
+
+@pytest.mark.parametrize("shape", ["banded", "one_strip", "few_long_rows", "duplicate_columns", "dense_column"])
+def test_tiled_engine_adversarial_structure(gpu, oracle, shape):
+    """Structures that stress the cells of the tiled engine: every entry of a row in one strip
+    (banded), every entry of the matrix in one strip, rows far longer than the long-row limit,
+    repeated (row, column) pairs, one column referenced by every row."""
+    rng = np.random.default_rng(17)
+    if shape == "banded":
+        rows = cols = 300_000
+        lens = np.full(rows, 16)
+        rp, ci, va = _csr_from_lengths_and_cols(lens, lambda r, s: np.clip(r - 8 + s, 0, cols - 1), rng)
+    elif shape == "one_strip":
+        rows, cols = 400_000, 200_000
+        lens = np.full(rows, 8)
+        rp, ci, va = _csr_from_lengths_and_cols(lens, lambda r, s: (r * 7 + s * 13) % 3000, rng)
+    elif shape == "few_long_rows":
+        rows, cols = 3_000, 1_000_000
+        lens = np.full(rows, 700)
+        lens[::97] = 0
+        rp, ci, va = _csr_from_lengths_and_cols(lens, lambda r, s: (s * 1427 + r * 31) % cols, rng)
+    elif shape == "duplicate_columns":
+        rows, cols = 200_000, 150_000
+        lens = np.full(rows, 10)
+        rp, ci, va = _csr_from_lengths_and_cols(lens, lambda r, s: (r * 3 + (s // 2) * 50_021) % cols, rng)
+    else:
+        rows, cols = 500_000, 100_000
+        lens = np.full(rows, 4)
+        rp, ci, va = _csr_from_lengths_and_cols(lens, lambda r, s: np.where(s == 0, 77, (r * 5 + s * 33_331) % cols), rng)
+    x = gpu.synth.vector(17, 1, cols)
+    want = oracle.spmv_csr(rp, ci, va, x)
+    got = run_tiled(gpu, rp, ci, va, cols, x, kernel=2)
+    assert reorder_err(rp, ci, va, x, want, got) <= REORDER_TOL

@@ -199,6 +199,7 @@ _SIGNATURES = {
     "spmv_c_pr_step_push": (c_int, [c_void_p, c_void_p, c_void_p, c_float, POINTER(c_void_p), c_int, c_void_p]),
     "spmv_c_pr_reduce": (c_int, [c_void_p, c_void_p, c_void_p]),
     "spmv_c_pr_commit": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
+    "spmv_c_pr_reduce_commit": (c_int, [c_void_p, c_float, c_void_p]),
     "spmv_c_pr_commit_gathered": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_float, c_void_p]),
     "spmv_c_pr_status_get": (c_int, [c_void_p, POINTER(PrStatus), c_void_p]),
     "spmv_c_pr_column_sums": (c_int, [POINTER(CSRMatrix), c_void_p, c_void_p]),

@@ -414,6 +414,11 @@ int spmv_c_pr_commit(spmv_c_pr_shard* h, const double* d_sums, float tolerance, 
     return launch_code(detail::pr_commit(h->shard, d_sums, tolerance, as_stream(hip_stream)));
 }
 
+int spmv_c_pr_reduce_commit(spmv_c_pr_shard* h, float tolerance, void* hip_stream) {
+    if (!h) return kInvalidArgument;
+    return launch_code(detail::pr_reduce_commit(h->shard, tolerance, as_stream(hip_stream)));
+}
+
 int spmv_c_pr_commit_gathered(spmv_c_pr_shard* h, const float* d_gathered, int world, int64_t stride,
                               int64_t shard_len, float tolerance, void* hip_stream) {
     if (!h || !d_gathered || world < 1 || stride < shard_len + 4 || (stride & 1) || (shard_len & 1)) {

@@ -105,6 +105,29 @@ void pr_reduce_kernel(const double* __restrict__ block_partials, int num_blocks,
     }
 }
 
+// Single-rank form: fold the block partials and apply them in one launch.
+__global__ __launch_bounds__(kBlock)
+void pr_reduce_commit_kernel(const double* __restrict__ block_partials, int num_blocks, float tolerance,
+                             PrState* __restrict__ state) {
+    if (state->done) return;
+    double res2 = 0.0, mass = 0.0;
+    for (int b = threadIdx.x; b < num_blocks; b += kBlock) {
+        res2 += block_partials[2 * b];
+        mass += block_partials[2 * b + 1];
+    }
+    block_sum2(res2, mass);
+    if (threadIdx.x == 0) {
+        const float residual = static_cast<float>(sqrt(res2));
+        state->iterations += 1;
+        state->final_residual = residual;
+        state->dangling_sum = static_cast<float>(mass);
+        if (residual < tolerance) {
+            state->converged = 1;
+            state->done = 1;
+        }
+    }
+}
+
 // Applies the (already globally reduced) sums: residual, iteration count,
 // convergence flag, dangling mass for the next step.
 __global__ void pr_commit_kernel(const double* __restrict__ sums, float tolerance,
@@ -269,6 +292,12 @@ hipError_t pr_reduce(const PrShard& sh, double* d_sums, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t pr_reduce_commit(const PrShard& sh, float tolerance, hipStream_t s) {
+    pr_reduce_commit_kernel<<<1, kBlock, 0, s>>>(sh.d_block_partials, sh.local_rows > 0 ? sh.grid : 0, tolerance,
+                                                 sh.d_state);
+    return hipGetLastError();
+}
+
 hipError_t pr_commit(const PrShard& sh, const double* d_sums, float tolerance, hipStream_t s) {
     pr_commit_kernel<<<1, 1, 0, s>>>(d_sums, tolerance, sh.d_state);
     return hipGetLastError();
@@ -429,8 +458,7 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
         const float* r_old = bufs[iter & 1];
         float* r_new = bufs[(iter + 1) & 1];
         ok = detail::pr_step(shard, r_old, r_new, config->damping_factor, detail::PushTargets{}, stream) == hipSuccess
-          && detail::pr_reduce(shard, sums.ptr, stream) == hipSuccess
-          && detail::pr_commit(shard, sums.ptr, config->tolerance, stream) == hipSuccess
+          && detail::pr_reduce_commit(shard, config->tolerance, stream) == hipSuccess
           && hipMemcpyAsync(&pinned[iter & 1], state.ptr, sizeof(PrState),
                             hipMemcpyDeviceToHost, stream) == hipSuccess
           && hipEventRecord(seen[iter & 1], stream) == hipSuccess;

@@ -52,6 +52,7 @@ hipError_t pr_step(const PrShard& shard, const float* d_r_old, float* d_r_new, f
                    const PushTargets& push, hipStream_t s);
 hipError_t pr_reduce(const PrShard& shard, double* d_sums /*[2]*/, hipStream_t s);
 hipError_t pr_commit(const PrShard& shard, const double* d_sums, float tolerance, hipStream_t s);
+hipError_t pr_reduce_commit(const PrShard& shard, float tolerance, hipStream_t s);   // single rank: both in one launch
 hipError_t pr_commit_gathered(const PrShard& shard, const float* d_gathered, int world, long long stride,
                               long long shard_len, float tolerance, hipStream_t s);
 hipError_t pr_fill(float* d_r, size_t n, float value, hipStream_t s);

@@ -162,6 +162,12 @@ class HipEngine:
         self._check(lib().spmv_c_pr_reduce(self._shard, c_void_p(target.data_ptr()), self._stream()), "pr_reduce")
         return target
 
+    def step_and_commit(self, r_old: torch.Tensor, r_new: torch.Tensor, damping: float, tolerance: float) -> None:
+        """Single-rank iteration: the step, then reduce + commit in one launch."""
+        self._check(lib().spmv_c_pr_step(self._shard, c_void_p(r_old.data_ptr()), c_void_p(r_new.data_ptr()),
+                                         damping, self._stream()), "pr_step")
+        self._check(lib().spmv_c_pr_reduce_commit(self._shard, tolerance, self._stream()), "pr_reduce_commit")
+
     def commit(self, sums: torch.Tensor, tolerance: float) -> None:
         self._check(lib().spmv_c_pr_commit(self._shard, c_void_p(sums.data_ptr()), tolerance, self._stream()),
                     "pr_commit")
@@ -327,8 +333,10 @@ class ShardedPageRank:
         """Enqueue iteration k (0-based): r[k & 1] -> r[(k + 1) & 1]."""
         r_old, r_new = self.r[k & 1], self.r[(k + 1) & 1]
         if self.world == 1:
-            sums = self.engine.step(r_old, r_new, damping)
-            self.engine.commit(sums, tolerance)
+            if hasattr(self.engine, "step_and_commit"):
+                self.engine.step_and_commit(r_old, r_new, damping, tolerance)
+            else:
+                self.engine.commit(self.engine.step(r_old, r_new, damping), tolerance)
             return
         if self.mode == "push":
             sums = self.engine.step(r_old, r_new, damping, push_to=self._peer_ptrs[(k + 1) & 1])

@@ -239,6 +239,8 @@ int spmv_c_pr_step_push(spmv_c_pr_shard* shard, const float* d_r_old, float* d_r
                         float* const* peer_r_new, int num_peers, void* hip_stream);
 int spmv_c_pr_reduce(spmv_c_pr_shard* shard, double* d_sums /*[2]*/, void* hip_stream);
 int spmv_c_pr_commit(spmv_c_pr_shard* shard, const double* d_sums, float tolerance, void* hip_stream);
+/* single rank: reduce + commit in one launch (no sums buffer leaves the engine) */
+int spmv_c_pr_reduce_commit(spmv_c_pr_shard* shard, float tolerance, void* hip_stream);
 /* multi-rank commit without an all-reduce: rank p's two partial sums (as doubles) sit in the 16-byte
  * tail of its slice, d_gathered[p * stride + shard_len ...]; stride >= shard_len + 4, both even */
 int spmv_c_pr_commit_gathered(spmv_c_pr_shard* shard, const float* d_gathered, int world, int64_t stride,

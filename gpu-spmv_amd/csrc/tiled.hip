@@ -588,7 +588,9 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     const long long cells = static_cast<long long>(plan->num_strips) * plan->num_tiles;
     // A row spreads over the strips; once it averages more than ~2 entries per cell its lanes
     // start to collide on one LDS word in phase 2, so such rows take the direct path instead.
-    plan->long_row = A ? std::max(64, std::min(kMaxLongRow, 2 * plan->num_strips)) : 0x7fffffff;
+    int long_factor = 2;
+    if (const char* env = std::getenv("SPMV_TILED_LONG_FACTOR")) long_factor = std::max(1, std::atoi(env));
+    plan->long_row = A ? std::max(64, std::min(kMaxLongRow, long_factor * plan->num_strips)) : 0x7fffffff;
     const long long long_capacity = src.nnz / plan->long_row + 1;
 
     int *cnt = nullptr, *offs = nullptr, *strip_begin = nullptr, *num_long = nullptr;

@@ -162,3 +162,62 @@ def test_ell_from_csr_on_the_device_matches_the_host_conversion(gpu, oracle):
     gpu.ell_destroy(E2)
     gpu.csr_destroy(B)
     gpu.csr_destroy(A)
+
+
+def test_async_spmv_and_pagerank_steps_replay_from_a_hip_graph(gpu, oracle):
+    """The enqueue-only entry points are graph-safe once a matrix's auxiliary data exists:
+    capture (a) one LDS-tiled SpMV and (b) two ping-pong PageRank steps into hipGraphs (through
+    torch's capture API, which records whatever lands on its capture stream) and replay them."""
+    torch = pytest.importorskip("torch")
+    prd = importlib.import_module("gpu-spmv_amd.pagerank_dist")
+    n = 200_000
+    rp, ci, _ = gpu.synth.uniform_csr(6, 0, n, n, 8)
+    va = gpu.synth.column_stochastic_values(ci, n)
+    A = gpu.csr_from_arrays(n, n, rp, ci, va)
+    gpu.csr_to_gpu(A)
+    x = gpu.synth.vector(6, 1, n)
+    tx, ty = torch.from_numpy(x).cuda(), torch.zeros(n, device="cuda")
+    cfg = gpu.SpMVConfig(kernel_type=1, use_texture=True)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                            # warm-up outside capture: builds the plan
+        assert gpu.spmv_csr_async(A, tx.data_ptr(), ty.data_ptr(), cfg, n, side.cuda_stream) == 0
+    side.synchronize()
+    assert gpu.csr_has_tiled_plan(A)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        assert gpu.spmv_csr_async(A, tx.data_ptr(), ty.data_ptr(), cfg, n,
+                                  torch.cuda.current_stream().cuda_stream) == 0
+    ty.zero_()
+    tx.copy_(torch.from_numpy((2 * x).astype(np.float32)))   # new input, same graph
+    graph.replay()
+    torch.cuda.synchronize()
+    want = oracle.spmv_csr(rp, ci, va, (2 * x).astype(np.float32))
+    assert np.max(np.abs(ty.cpu().numpy() - want)) <= 1e-5 * max(1.0, float(np.abs(want).max()))
+
+    # (b) PageRank: graph of two steps (A -> B -> A), replayed; equals the eager loop
+    lay = prd.Layout(n)
+    dev = torch.device("cuda:0")
+    eng = prd.HipEngine(torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev), lay)
+    pr = prd.ShardedPageRank(eng, lay).prepare()
+    pr.reset()
+    for k in range(6):
+        pr.iterate(k, 0.85, 0.0)
+    torch.cuda.synchronize()
+    eager = pr.r[0].clone()
+    pr.reset()
+    pr.iterate(0, 0.85, 0.0)                                  # warm-up pair outside capture
+    pr.iterate(1, 0.85, 0.0)
+    torch.cuda.synchronize()
+    pr.reset()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        pr.iterate(0, 0.85, 0.0)
+        pr.iterate(1, 0.85, 0.0)
+    pr.reset()
+    for _ in range(3):
+        g2.replay()
+    torch.cuda.synchronize()
+    assert eng.status()[0] == 6
+    torch.testing.assert_close(pr.r[0], eager, rtol=2e-6, atol=0)
+    eng.close()
+    gpu.csr_destroy(A)

@@ -236,14 +236,12 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
 
+    if rank == 0:
+        print(json.dumps(result), flush=True)      # before teardown: the line is out whatever happens next
     engine.close()
-    if world > 1:
-        dist.barrier()
-    pr.close()
+    pr.close()          # unmaps peers, barriers, then frees the rank vectors
     if world > 1:
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(result), flush=True)
 
 
 def api_table(spmv, wl, engine, n, k, seed):

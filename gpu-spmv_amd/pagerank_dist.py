@@ -228,12 +228,25 @@ class ShardedPageRank:
         t.zero_()
         return t
 
-    def close(self):
-        """Unmap the peers' vectors and free the rank vectors (the engine is closed by its owner)."""
+    def close_peers(self):
+        """Unmap the peers' vectors (every rank must do this before anybody frees its own)."""
         for p in self._peer_keepalive:
             lib().spmv_c_ipc_close(c_void_p(p))
         self._peer_keepalive = []
         self._peer_ptrs = None
+        if self.mode == "push":
+            self.mode = "gather"
+
+    def close(self):
+        """Unmap the peers' vectors, then (after a barrier when ranks share mappings) free the rank
+        vectors.  The engine is closed by its owner."""
+        had_peers = bool(self._peer_keepalive)
+        self.close_peers()
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)      # nobody frees a vector a peer still has mapped
+        del had_peers
         self.r = []
         for ptr in self._owned:
             lib().spmv_c_device_free(ptr)

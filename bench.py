@@ -195,12 +195,14 @@ def main():
         except Exception:
             traffic = None
     tiled = spmv.csr_has_tiled_plan(engine._A)
+    plan_info = spmv.csr_tiled_info(engine._A)
     step_kernels = ("tiled_expand_kernel + tiled_pagerank_reduce_kernel (LDS-tiled SpMV step, two launches)"
                     if tiled else "pr_step_kernel (fused vector-CSR SpMV + PageRank update)")
     roofline = {"bound": "hbm", "kernel": step_kernels,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": local_bytes}
+                "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": local_bytes,
+                "tiled_plan": plan_info}
 
     result = {
         "metric": "spmv_effective_bandwidth", "value": round(value, 1), "unit": "GB/s",

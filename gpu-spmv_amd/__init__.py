@@ -182,6 +182,8 @@ _SIGNATURES = {
     "spmv_c_auto_config": (c_int, [POINTER(CSRMatrix), POINTER(SpMVConfig)]),
     "spmv_c_validate_dimensions": (c_int, [c_int, c_int]),
     "spmv_c_csr_has_tiled_plan": (c_int, [POINTER(CSRMatrix)]),
+    "spmv_c_tiled_shape": (c_int, [c_int64, c_int64, c_int64, POINTER(c_int32), POINTER(c_int32)]),
+    "spmv_c_csr_tiled_info": (c_int, [POINTER(CSRMatrix), POINTER(c_int64)]),
     "spmv_c_spmv_csr_async": (c_int, [POINTER(CSRMatrix), c_void_p, c_void_p, POINTER(SpMVConfig), c_int,
                                       c_void_p]),
     "spmv_c_spmv_ell_async": (c_int, [POINTER(ELLMatrix), c_void_p, c_void_p, POINTER(SpMVConfig), c_int,
@@ -585,6 +587,23 @@ def spmv_ell(A, d_x, d_y, config=None, vec_size=-1) -> SpMVResult:
 
 def csr_has_tiled_plan(A) -> bool:
     return bool(lib().spmv_c_csr_has_tiled_plan(A))
+
+
+def tiled_shape(rows, cols, nnz):
+    """(takes_it, strip_cols, tile_rows) the LDS-tiled engine would use for such a matrix."""
+    w, r = c_int32(0), c_int32(0)
+    takes = lib().spmv_c_tiled_shape(rows, cols, nnz, byref(w), byref(r))
+    return bool(takes), w.value, r.value
+
+
+def csr_tiled_info(A):
+    """dict describing the matrix's cached tiled plan, or None."""
+    out = (c_int64 * 8)()
+    if not lib().spmv_c_csr_tiled_info(A, out):
+        return None
+    keys = ("strip_cols", "tile_rows", "num_strips", "num_tiles", "entries_in_cells", "long_rows",
+            "chunks_per_pass", "long_row_limit")
+    return dict(zip(keys, (int(v) for v in out)))
 
 
 def spmv_csr_async(A, d_x, d_y, config=None, vec_size=-1, stream=None) -> int:

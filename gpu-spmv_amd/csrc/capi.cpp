@@ -286,6 +286,26 @@ int spmv_c_csr_has_tiled_plan(const spmv_c_csr* A_c) {
     return aux && aux->tiled ? 1 : 0;
 }
 
+int spmv_c_tiled_shape(int64_t rows, int64_t cols, int64_t nnz, int32_t* strip_cols, int32_t* tile_rows) {
+    int w = 0, r = 0;
+    const bool takes = detail::tiled_shape_for(rows, cols, nnz, &w, &r);
+    if (strip_cols) *strip_cols = w;
+    if (tile_rows) *tile_rows = r;
+    return takes ? 1 : 0;
+}
+
+int spmv_c_csr_tiled_info(const spmv_c_csr* A_c, int64_t out[8]) {
+    const CSRMatrix* A = cxx(A_c);
+    if (!A || !A->d_row_ptrs || !out) return 0;
+    detail::CsrAux* aux = detail::aux_lookup(A->d_row_ptrs, false);
+    if (!aux || !aux->tiled) return 0;
+    const detail::TiledPlan& p = *aux->tiled;
+    const int64_t v[8] = {p.strip_cols, p.tile_rows, p.num_strips, p.num_tiles, p.nnz, p.num_long, p.run_chunks,
+                          p.long_row};
+    std::memcpy(out, v, sizeof(v));
+    return 1;
+}
+
 int spmv_c_spmv_csr_async(const spmv_c_csr* A, const float* d_x, float* d_y,
                           const spmv_c_config* config, int vec_size, void* hip_stream) {
     return spmv_csr_async(cxx(A), d_x, d_y, cxx(config), vec_size, as_stream(hip_stream));

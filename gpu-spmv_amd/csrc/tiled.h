@@ -48,6 +48,10 @@ struct TiledPlan {
     long long    csr_nnz = 0;
 };
 
+// the (strip columns, tile rows) the engine would pick for a matrix of this shape, and whether it
+// would take the matrix at all (pure host logic; exposed for tests and reports)
+bool tiled_shape_for(long long rows, long long cols, long long nnz, int* strip_cols, int* tile_rows);
+
 // true when the matrix is worth (and able) to run through the tiled engine
 bool tiled_eligible(const CSRMatrix* A);
 bool tiled_eligible(const ELLMatrix* A);

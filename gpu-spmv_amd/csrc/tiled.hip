@@ -533,6 +533,14 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s);
 
 } // namespace
 
+bool tiled_shape_for(long long rows, long long cols, long long nnz, int* strip_cols, int* tile_rows) {
+    int w = 0, r = 0;
+    if (rows > 0 && cols > 0 && nnz > 0) choose_shape(rows, cols, nnz, &w, &r);
+    if (strip_cols) *strip_cols = w;
+    if (tile_rows) *tile_rows = r;
+    return eligible_dims(rows, cols, nnz);
+}
+
 bool tiled_eligible(const CSRMatrix* A) {
     return A && eligible_dims(A->num_rows, A->num_cols, A->nnz);
 }

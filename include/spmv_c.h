@@ -189,6 +189,12 @@ int spmv_c_validate_dimensions(int num_cols, int vec_size);               /* 1 =
 /* extension: 1 when the matrix currently holds an LDS-tiled plan (built by the first
  * use_texture call / PageRank on a large matrix), 0 otherwise */
 int spmv_c_csr_has_tiled_plan(const spmv_c_csr* A);
+/* extension: what the LDS-tiled engine would do with a rows x cols matrix of nnz entries: returns 1
+ * when it would take it (use_texture), and the strip width / tile height it would use (host logic) */
+int spmv_c_tiled_shape(int64_t rows, int64_t cols, int64_t nnz, int32_t* strip_cols, int32_t* tile_rows);
+/* extension: the plan a matrix currently holds — out[8] = strip_cols, tile_rows, num_strips, num_tiles,
+ * entries in cells, long rows, 64-entry chunks per phase-2 pass, long-row limit; returns 0 if none */
+int spmv_c_csr_tiled_info(const spmv_c_csr* A, int64_t out[8]);
 /* extension: enqueue on a caller stream without timing or synchronisation */
 int spmv_c_spmv_csr_async(const spmv_c_csr* A, const float* d_x, float* d_y,
                           const spmv_c_config* config, int vec_size, void* hip_stream);

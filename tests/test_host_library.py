@@ -282,3 +282,25 @@ def test_container_properties_random(spmv, tmp_path):
             spmv.ell_destroy(h)
         spmv.csr_destroy(A)
         spmv.csr_destroy(B)
+
+
+def test_tiled_engine_shape_rules(spmv):
+    """Host logic of the LDS-tiled engine (csrc/tiled.hip choose_shape / eligibility), no GPU needed:
+    which matrices it takes, and that strips / tiles stay inside the LDS budgets and index widths."""
+    takes, w, r = spmv.tiled_shape(10_000_000, 10_000_000, 160_000_000)          # BASELINE config 5
+    assert takes and w in (4096, 8192, 16384, 32768) and r in (1024, 2048, 4096, 8192)
+    assert (10_000_000 + r - 1) // r >= 1024                                       # enough row tiles to fill the chip
+    assert 160_000_000 / (((10_000_000 + w - 1) // w) * ((10_000_000 + r - 1) // r)) >= 100   # long enough runs
+    takes, w, r = spmv.tiled_shape(1_250_000, 10_000_032, 20_000_000)              # a 1/8 row shard of it
+    assert takes and w == 32768 and (1_250_000 + r - 1) // r >= 600
+    assert spmv.tiled_shape(1_000_000, 1_000_000, 16_000_000)[0]                   # config 2
+    assert not spmv.tiled_shape(1000, 1000, 8000)[0]                               # config 1: tiny
+    assert not spmv.tiled_shape(2_000_000, 30_000, 32_000_000)[0]                  # x fits LDS: other kernel
+    assert not spmv.tiled_shape(100_000, 1_000_000, 500_000)[0]                    # too few entries
+    assert not spmv.tiled_shape(2_000_000_000, 2_000_000_000, 2_000_000_000)[0]    # cell table would be too large
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        rows, cols = int(rng.integers(1, 50_000_000)), int(rng.integers(1, 50_000_000))
+        nnz = int(rng.integers(1, 2_000_000_000))
+        takes, w, r = spmv.tiled_shape(rows, cols, nnz)
+        assert w in (4096, 8192, 16384, 32768) and r in (1024, 2048, 4096, 8192)   # u16 local indices, LDS fits

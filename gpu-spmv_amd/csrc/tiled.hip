@@ -12,11 +12,11 @@
 //
 //   layout : entries sorted by cell = (column strip, row tile), strip-major; per entry
 //        value f32, local column u16, local row u16 (8 B, as CSR's 8 B) + a product slot.
-//   phase 1 "expand" : a workgroup loads one x strip (W = 16384 columns = 64 KiB) into
-//        LDS, streams its share of the strip's entries (value, local column) with
+//   phase 1 "expand" : a workgroup loads one x strip (W = 4 K .. 32 K columns, chosen per
+//        matrix = 16 .. 128 KiB) into LDS, streams its share of the strip's entries (value, local column) with
 //        16-byte loads, gathers x from LDS and stores the products — same order, so
 //        loads and stores are all contiguous.
-//   phase 2 "reduce" : a workgroup owns one row tile (R = 8192 rows = 32 KiB of LDS).
+//   phase 2 "reduce" : a workgroup owns one row tile (R = 1 K .. 8 K rows = 4 .. 32 KiB of LDS).
 //        The tile's entries are one contiguous run per strip (cell table); the waves
 //        walk the runs, add each product into the LDS tile and finally write the tile
 //        out with coalesced stores (optionally through the fused PageRank update).

@@ -11,6 +11,17 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
+def test_benchmark_executable_runs(gpu):
+    """benchmarks/spmv_benchmark.cpp: the working counterpart of the reference's benchmarks/main.cu."""
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "spmv_benchmark")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe, "200000", "300000", "8"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for needle in ("scalar CSR", "vector CSR", "merge path", "ELL", "speed-up GPU/CPU", "\"gflops\"",
+                   "iterations", "% of peak", "auto config"):
+        assert needle in out.stdout, needle
+
+
 def test_cpp_dropin_caller(gpu):
     exe = os.path.join(ROOT, "tests", "cpp", "bin", "dropin_smoke")
     assert os.path.exists(exe), "run __graft_entry__.build() first"

@@ -184,6 +184,7 @@ _SIGNATURES = {
     "spmv_c_csr_has_tiled_plan": (c_int, [POINTER(CSRMatrix)]),
     "spmv_c_tiled_shape": (c_int, [c_int64, c_int64, c_int64, POINTER(c_int32), POINTER(c_int32)]),
     "spmv_c_csr_tiled_info": (c_int, [POINTER(CSRMatrix), POINTER(c_int64)]),
+    "spmv_c_csr_tiled_folded": (c_int, [POINTER(CSRMatrix)]),
     "spmv_c_spmv_csr_async": (c_int, [POINTER(CSRMatrix), c_void_p, c_void_p, POINTER(SpMVConfig), c_int,
                                       c_void_p]),
     "spmv_c_spmv_ell_async": (c_int, [POINTER(ELLMatrix), c_void_p, c_void_p, POINTER(SpMVConfig), c_int,
@@ -603,7 +604,9 @@ def csr_tiled_info(A):
         return None
     keys = ("strip_cols", "tile_rows", "num_strips", "num_tiles", "entries_in_cells", "long_rows",
             "chunks_per_pass", "long_row_limit")
-    return dict(zip(keys, (int(v) for v in out)))
+    info = dict(zip(keys, (int(v) for v in out)))
+    info["values_folded"] = bool(lib().spmv_c_csr_tiled_folded(A))
+    return info
 
 
 def spmv_csr_async(A, d_x, d_y, config=None, vec_size=-1, stream=None) -> int:

@@ -306,6 +306,13 @@ int spmv_c_csr_tiled_info(const spmv_c_csr* A_c, int64_t out[8]) {
     return 1;
 }
 
+int spmv_c_csr_tiled_folded(const spmv_c_csr* A_c) {
+    const CSRMatrix* A = cxx(A_c);
+    if (!A || !A->d_row_ptrs) return 0;
+    detail::CsrAux* aux = detail::aux_lookup(A->d_row_ptrs, false);
+    return aux && aux->tiled && aux->tiled->col_weight ? 1 : 0;
+}
+
 int spmv_c_spmv_csr_async(const spmv_c_csr* A, const float* d_x, float* d_y,
                           const spmv_c_config* config, int vec_size, void* hip_stream) {
     return spmv_csr_async(cxx(A), d_x, d_y, cxx(config), vec_size, as_stream(hip_stream));

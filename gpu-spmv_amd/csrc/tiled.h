@@ -25,7 +25,8 @@ struct TiledPlan {
     int run_chunks = 2;             // 64-entry chunks read from a run per phase-2 pass (1, 2 or 4)
 
     // entries sorted by cell (strip-major, tile inside a strip)
-    float*    a_val = nullptr;      // [nnz]
+    float*    a_val = nullptr;      // [nnz]; null when the values are folded into col_weight
+    float*    col_weight = nullptr; // [num_cols] the one value every entry of a column carries, or null
     uint16_t* a_lcol = nullptr;     // [nnz] column - strip * W
     uint16_t* a_lrow = nullptr;     // [nnz] row - tile * R
     float*    prod = nullptr;       // [nnz] phase-1 output / phase-2 input, same order

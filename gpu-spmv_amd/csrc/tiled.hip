@@ -61,7 +61,10 @@ constexpr int kLongChunk = 512;       // entries per wavefront of the long-row p
 constexpr long long kMaxCells = 1LL << 26;
 constexpr long long kTargetRun = 128;   // wanted mean entries per cell (run length seen by phase 2)
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------ plan building ----
 // LANES lanes walk one row; every entry of a short row is assigned to cell (strip, tile).
@@ -95,7 +98,7 @@ void bucket_kernel(int num_rows, int num_tiles, int strip_cols, int tile_rows, i
             atomicAdd(&cell_counter[cell], 1);
         } else {
             const int at = offs[cell] + atomicAdd(&cell_counter[cell], 1);
-            a_val[at] = vals[j];
+            if (a_val) a_val[at] = vals[j];
             a_lcol[at] = static_cast<unsigned short>(c - strip * strip_cols);
             a_lrow[at] = lrow;
         }
@@ -124,7 +127,7 @@ void bucket_ell_kernel(int num_rows, int width, int num_tiles, int strip_cols, i
             atomicAdd(&cell_counter[cell], 1);
         } else {
             const int at = offs[cell] + atomicAdd(&cell_counter[cell], 1);
-            a_val[at] = vals[slot];
+            if (a_val) a_val[at] = vals[slot];
             a_lcol[at] = static_cast<unsigned short>(c - strip * strip_cols);
             a_lrow[at] = lrow;
         }
@@ -155,6 +158,29 @@ void exclusive_scan_kernel(const int* __restrict__ in, long long n, int* __restr
         run += in[i];
     }
     if (threadIdx.x == 1023) out[n] = static_cast<int>(s_part[1023]);
+}
+
+// Column-weight folding: when every stored entry of a column carries the same value
+// (adjacency matrices, the column-stochastic matrices of PageRank: a_ij = 1 / outdeg(j)),
+// a_ij * x_j = (w_j * x_j) is one product per column instead of one per entry, and phase 1 no
+// longer needs the value stream.  PASS 0 records a value per column, PASS 1 compares every entry
+// with it bit for bit; the plan folds only if none differs.  Padding (col < 0) is skipped.
+template <int PASS>
+__global__ __launch_bounds__(kBlock)
+void column_weight_probe_kernel(const int* __restrict__ cols, const float* __restrict__ vals, long long count,
+                                float* __restrict__ weight, int* __restrict__ differs) {
+    bool bad = false;
+    for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < count;
+         i += static_cast<long long>(gridDim.x) * kBlock) {
+        const int c = cols[i];
+        if (c < 0) continue;
+        if (PASS == 0) {
+            weight[c] = vals[i];
+        } else {
+            bad |= __float_as_uint(weight[c]) != __float_as_uint(vals[i]);
+        }
+    }
+    if (PASS == 1 && bad) *differs = 1;
 }
 
 // cells_t[tile * num_strips + strip] = (begin, length) of the cell's run;
@@ -197,11 +223,14 @@ __device__ __forceinline__ void long_row_chunk(const LongRows& lr, int which, co
     if ((threadIdx.x & 63) == 0) atomicAdd(&lr.seed[row], acc);
 }
 
-template <int W, int kExpandBlock>
+// FOLD: the plan holds one weight per column instead of a value per entry; the strip is staged
+// as w_j * x_j and an entry's product is a plain LDS read (the same rounded product as a_ij * x_j).
+template <int W, int kExpandBlock, bool FOLD>
 __global__ __launch_bounds__(kExpandBlock)
 void tiled_expand_kernel(const int* __restrict__ items, int long_blocks,
                          const float* __restrict__ a_val,
                          const unsigned short* __restrict__ a_lcol,
+                         const float* __restrict__ col_weight,
                          const float* __restrict__ x, int num_cols,
                          float* __restrict__ prod, LongRows long_rows) {
     if (static_cast<int>(blockIdx.x) < long_blocks) {     // the long-row workgroups go first (latency-bound)
@@ -218,7 +247,24 @@ void tiled_expand_kernel(const int* __restrict__ items, int long_blocks,
     const long long base = static_cast<long long>(strip) * W;
     const int width = static_cast<int>(min(static_cast<long long>(W), num_cols - base));
     const float* src = x + base;
-    if ((reinterpret_cast<unsigned long long>(src) & 15) == 0) {
+    if (FOLD) {
+        const float* wsrc = col_weight + base;            // hipMalloc'd and base % 4 == 0: always aligned
+        const bool aligned = (reinterpret_cast<unsigned long long>(src) & 15) == 0;
+        for (int i = threadIdx.x * 4; i < width; i += kExpandBlock * 4) {
+            if (aligned && i + 3 < width) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(src + i);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wsrc + i);
+                f32x4 z;
+                z[0] = __fmul_rn(wv[0], xv[0]);
+                z[1] = __fmul_rn(wv[1], xv[1]);
+                z[2] = __fmul_rn(wv[2], xv[2]);
+                z[3] = __fmul_rn(wv[3], xv[3]);
+                *reinterpret_cast<f32x4*>(xs + i) = z;
+            } else {
+                for (int k = i; k < min(i + 4, width); ++k) xs[k] = __fmul_rn(wsrc[k], src[k]);
+            }
+        }
+    } else if ((reinterpret_cast<unsigned long long>(src) & 15) == 0) {
         for (int i = threadIdx.x * 4; i < width; i += kExpandBlock * 4) {
             if (i + 3 < width) {
                 *reinterpret_cast<f32x4*>(xs + i) = *reinterpret_cast<const f32x4*>(src + i);
@@ -231,19 +277,44 @@ void tiled_expand_kernel(const int* __restrict__ items, int long_blocks,
     }
     __syncthreads();
 
+    if (FOLD) {
+        // eight entries per lane per step: one 16-byte index load, two 16-byte product stores
+        for (int q = (begin & ~7) + threadIdx.x * 8; q < end; q += kExpandBlock * 8) {
+            if (q >= begin && q + 7 < end) {
+                const u16x8 c = *reinterpret_cast<const u16x8*>(a_lcol + q);
+                f32x4 lo, hi;
+                lo[0] = xs[c[0]]; lo[1] = xs[c[1]]; lo[2] = xs[c[2]]; lo[3] = xs[c[3]];
+                hi[0] = xs[c[4]]; hi[1] = xs[c[5]]; hi[2] = xs[c[6]]; hi[3] = xs[c[7]];
+                *reinterpret_cast<f32x4*>(prod + q) = lo;
+                *reinterpret_cast<f32x4*>(prod + q + 4) = hi;
+            } else {
+                for (int k = max(q, begin); k < min(q + 8, end); ++k) prod[k] = xs[a_lcol[k]];
+            }
+        }
+        return;
+    }
     // four entries per lane per step, groups aligned to 4 entries (16-byte loads and stores)
     for (int q = (begin & ~3) + threadIdx.x * 4; q < end; q += kExpandBlock * 4) {
         if (q >= begin && q + 3 < end) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(a_val + q);
             const u16x4 c = *reinterpret_cast<const u16x4*>(a_lcol + q);
             f32x4 p;
-            p[0] = v[0] * xs[c[0]];
-            p[1] = v[1] * xs[c[1]];
-            p[2] = v[2] * xs[c[2]];
-            p[3] = v[3] * xs[c[3]];
+            if (FOLD) {
+                p[0] = xs[c[0]];
+                p[1] = xs[c[1]];
+                p[2] = xs[c[2]];
+                p[3] = xs[c[3]];
+            } else {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a_val + q);
+                p[0] = v[0] * xs[c[0]];
+                p[1] = v[1] * xs[c[1]];
+                p[2] = v[2] * xs[c[2]];
+                p[3] = v[3] * xs[c[3]];
+            }
             *reinterpret_cast<f32x4*>(prod + q) = p;
         } else {
-            for (int k = max(q, begin); k < min(q + 4, end); ++k) prod[k] = a_val[k] * xs[a_lcol[k]];
+            for (int k = max(q, begin); k < min(q + 4, end); ++k) {
+                prod[k] = FOLD ? xs[a_lcol[k]] : a_val[k] * xs[a_lcol[k]];
+            }
         }
     }
 }
@@ -293,7 +364,7 @@ __device__ __forceinline__ void tile_accumulate(float* tile, int tile_index, int
         const int2 meta = s0 + lane < num_strips ? mine[s0 + lane] : make_int2(0, 0);
         const int runs = min(64, num_strips - s0);
         for (int k0 = wave * kRuns; k0 < runs; k0 += kWaves * kRuns) {
-            int begin[kRuns], len[kRuns];
+            int begin[kRuns], len[kRuns], lead[kRuns];
             int longest = 0;
 #pragma unroll
             for (int j = 0; j < kRuns; ++j) {
@@ -302,17 +373,50 @@ __device__ __forceinline__ void tile_accumulate(float* tile, int tile_index, int
                 len[j] = k0 + j < runs ? __shfl(meta.y, k, 64) : 0;
                 longest = max(longest, len[j]);
             }
+            if (U >= 2) {
+                // pairs of entries per lane (8-byte product / 4-byte row loads): runs re-based to an
+                // even entry, the odd leading entry masked off
+#pragma unroll
+                for (int j = 0; j < kRuns; ++j) {
+                    lead[j] = begin[j] & 1;
+                    len[j] += lead[j];
+                    begin[j] &= ~1;
+                }
+                longest += 1;
+            }
             for (int done = 0; done < longest; done += 64 * U) {
                 float p[8];
                 int r[8];
+                if (U >= 2) {
 #pragma unroll
-                for (int j = 0; j < kRuns; ++j) {
+                    for (int j = 0; j < kRuns; ++j) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int i = done + u * 64 + lane;
-                        const bool ok = i < len[j];
-                        p[j * U + u] = ok ? prod[begin[j] + i] : 0.0f;
-                        r[j * U + u] = ok ? a_lrow[begin[j] + i] : -1;
+                        for (int u = 0; u < U; u += 2) {
+                            const int i = done + u * 64 + 2 * lane;
+                            const bool ok = i < len[j];          // the pair is inside the allocation whenever its first entry is
+                            f32x2 pv = {0.0f, 0.0f};
+                            u16x2 rv = {0, 0};
+                            if (ok) {
+                                pv = *reinterpret_cast<const f32x2*>(prod + begin[j] + i);
+                                rv = *reinterpret_cast<const u16x2*>(a_lrow + begin[j] + i);
+                            }
+                            const bool first = ok && i >= lead[j];
+                            p[j * U + u] = pv[0];
+                            r[j * U + u] = first ? rv[0] : -1;
+                            p[j * U + u + 1] = pv[1];
+                            r[j * U + u + 1] = (ok && i + 1 < len[j]) ? rv[1] : -1;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kRuns; ++j) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int i = done + u * 64 + lane;
+                            const bool ok = i < len[j];
+                            p[j * U + u] = ok ? prod[begin[j] + i] : 0.0f;
+                            r[j * U + u] = ok ? a_lrow[begin[j] + i] : -1;
+                        }
                     }
                 }
 #pragma unroll
@@ -441,8 +545,13 @@ template <int W, int BLOCK>
 hipError_t launch_expand_as(const TiledPlan& plan, const float* d_x, hipStream_t s) {
     const LongRows lr{plan.long_chunks, plan.num_long_chunks, plan.csr_nnz, plan.csr_cols, plan.csr_vals, plan.seed};
     const int long_blocks = (plan.num_long_chunks + BLOCK / 64 - 1) / (BLOCK / 64);
-    tiled_expand_kernel<W, BLOCK><<<plan.num_items + long_blocks, BLOCK, 0, s>>>(
-        plan.items, long_blocks, plan.a_val, plan.a_lcol, d_x, plan.num_cols, plan.prod, lr);
+    if (plan.col_weight) {
+        tiled_expand_kernel<W, BLOCK, true><<<plan.num_items + long_blocks, BLOCK, 0, s>>>(
+            plan.items, long_blocks, nullptr, plan.a_lcol, plan.col_weight, d_x, plan.num_cols, plan.prod, lr);
+    } else {
+        tiled_expand_kernel<W, BLOCK, false><<<plan.num_items + long_blocks, BLOCK, 0, s>>>(
+            plan.items, long_blocks, plan.a_val, plan.a_lcol, nullptr, d_x, plan.num_cols, plan.prod, lr);
+    }
     return hipGetLastError();
 }
 
@@ -570,7 +679,7 @@ hipError_t tiled_build(const ELLMatrix* A, TiledPlan** out, hipStream_t s) {
 void tiled_free(TiledPlan* p) {
     if (!p) return;
     void* owned[] = {p->a_val, p->a_lcol, p->a_lrow, p->prod, p->cells_t, p->items, p->long_rows, p->long_chunks,
-                     p->seed};
+                     p->seed, p->col_weight};
     for (void* q : owned) if (q) (void)hipFree(q);
     delete p;
 }
@@ -694,7 +803,33 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         if (e != hipSuccess) return cleanup(e);
     }
 
-    e = dev_alloc(&plan->a_val, plan->nnz);
+    // column-weight folding (see column_weight_probe_kernel): on unless SPMV_TILED_FOLD=0
+    bool fold = true;
+    if (const char* env = std::getenv("SPMV_TILED_FOLD")) fold = env[0] != '0';
+    if (fold && plan->nnz > 0) {
+        const int* src_cols = A ? A->d_col_indices : src.ell->d_col_indices;
+        const float* src_vals = A ? A->d_values : src.ell->d_values;
+        int* differs = num_long;                       // its count is on the host already: reuse the word
+        const int grid = static_cast<int>(std::min<long long>((src.nnz + kBlock - 1) / kBlock, 16384));
+        e = dev_alloc(&plan->col_weight, plan->num_cols);
+        if (e == hipSuccess) e = hipMemsetAsync(plan->col_weight, 0, static_cast<size_t>(plan->num_cols) * sizeof(float), s);
+        if (e == hipSuccess) e = hipMemsetAsync(differs, 0, sizeof(int), s);
+        if (e == hipSuccess) {
+            column_weight_probe_kernel<0><<<grid, kBlock, 0, s>>>(src_cols, src_vals, src.nnz, plan->col_weight, differs);
+            column_weight_probe_kernel<1><<<grid, kBlock, 0, s>>>(src_cols, src_vals, src.nnz, plan->col_weight, differs);
+            e = hipGetLastError();
+        }
+        int host_differs = 1;
+        if (e == hipSuccess) e = hipMemcpyAsync(&host_differs, differs, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return cleanup(e);
+        if (host_differs) {
+            (void)hipFree(plan->col_weight);
+            plan->col_weight = nullptr;
+        }
+    }
+
+    if (!plan->col_weight) e = dev_alloc(&plan->a_val, plan->nnz);
     if (e == hipSuccess) e = dev_alloc(&plan->a_lcol, plan->nnz);
     if (e == hipSuccess) e = dev_alloc(&plan->a_lrow, plan->nnz);
     if (e == hipSuccess) e = dev_alloc(&plan->prod, plan->nnz);

@@ -195,6 +195,10 @@ int spmv_c_tiled_shape(int64_t rows, int64_t cols, int64_t nnz, int32_t* strip_c
 /* extension: the plan a matrix currently holds — out[8] = strip_cols, tile_rows, num_strips, num_tiles,
  * entries in cells, long rows, 64-entry chunks per phase-2 pass, long-row limit; returns 0 if none */
 int spmv_c_csr_tiled_info(const spmv_c_csr* A, int64_t out[8]);
+/* extension: 1 when the matrix's plan folded its values into one weight per column (every stored
+ * entry of a column bit-identical: adjacency / column-stochastic matrices), so that the tiled engine
+ * streams no values; 0 otherwise or without a plan.  SPMV_TILED_FOLD=0 at build time disables it. */
+int spmv_c_csr_tiled_folded(const spmv_c_csr* A);
 /* extension: enqueue on a caller stream without timing or synchronisation */
 int spmv_c_spmv_csr_async(const spmv_c_csr* A, const float* d_x, float* d_y,
                           const spmv_c_config* config, int vec_size, void* hip_stream);

@@ -286,6 +286,53 @@ def test_tiled_engine_nonnegative_relative_error(gpu, oracle):
     assert max_rel_err(oracle.spmv_csr(rp, ci, va, x), got) <= REORDER_TOL
 
 
+def _tiled_with_info(spmv, rp, ci, va, cols, x):
+    A = spmv.csr_from_arrays(len(rp) - 1, cols, rp, ci, va)
+    try:
+        assert spmv.csr_to_gpu(A) == 0
+        d_x, d_y = spmv.CudaBuffer(cols), spmv.CudaBuffer(len(rp) - 1)
+        d_x.copyFromHost(x, cols)
+        res = spmv.spmv_csr(A, d_x, d_y, spmv.SpMVConfig(kernel_type=1, use_texture=True), cols)
+        assert res.error_code == 0
+        return d_y.copyToHost(len(rp) - 1), spmv.csr_tiled_info(A)
+    finally:
+        spmv.csr_destroy(A)
+
+
+def test_tiled_engine_folds_column_uniform_values(gpu, oracle, monkeypatch):
+    """Every stored entry of a column equal (a_ij = 1 / outdeg(j), adjacency matrices): the plan keeps one
+    weight per column and streams no values; one differing entry, or SPMV_TILED_FOLD=0, keeps the value
+    stream.  All three agree with the oracle (the products are the same rounded numbers)."""
+    rows = cols = 400_000
+    lens = gpu.synth.power_law_lengths(9, rows, max_len=20000, n_cols=cols)       # long rows keep their CSR values
+    rp, ci, _ = gpu.synth.stratified_csr(9, 0, lens, cols)
+    outdeg = np.bincount(ci, minlength=cols)
+    va = (np.float32(1.0) / np.maximum(outdeg, 1).astype(np.float32))[ci]
+    x = np.abs(gpu.synth.vector(9, 1, cols)) + np.float32(0.01)
+    want = oracle.spmv_csr(rp, ci, va, x)
+
+    got, info = _tiled_with_info(gpu, rp, ci, va, cols, x)
+    assert info["values_folded"] and info["long_rows"] > 0
+    assert max_rel_err(want, got) <= REORDER_TOL
+
+    monkeypatch.setenv("SPMV_TILED_FOLD", "0")
+    got_plain, info = _tiled_with_info(gpu, rp, ci, va, cols, x)
+    assert not info["values_folded"]
+    assert max_rel_err(want, got_plain) <= REORDER_TOL
+    monkeypatch.delenv("SPMV_TILED_FOLD")
+
+    vb = va.copy()
+    vb[len(vb) // 2] = np.nextafter(vb[len(vb) // 2], np.float32(2.0))           # one entry one ulp off
+    got_b, info = _tiled_with_info(gpu, rp, ci, vb, cols, x)
+    assert not info["values_folded"]
+    assert max_rel_err(oracle.spmv_csr(rp, ci, vb, x), got_b) <= REORDER_TOL
+
+    ones = np.ones_like(va)                                                       # plain adjacency matrix
+    got_1, info = _tiled_with_info(gpu, rp, ci, ones, cols, x)
+    assert info["values_folded"]
+    assert max_rel_err(oracle.spmv_csr(rp, ci, ones, x), got_1) <= REORDER_TOL
+
+
 def test_use_texture_on_small_matrix_keeps_direct_kernels(gpu, oracle):
     """Below the size where x leaves L2 the hint is ignored (no plan is built)."""
     rp, ci, va = gpu.synth.uniform_csr(1, 0, 5000, 20000, 8)

@@ -59,7 +59,9 @@ constexpr int kMinItemEntries = 4096;
 constexpr int kMaxLongRow = 1024;     // rows longer than min(this, 2 * strips) bypass the cells
 constexpr int kLongChunk = 512;       // entries per wavefront of the long-row path
 constexpr long long kMaxCells = 1LL << 26;
-constexpr long long kTargetRun = 128;   // wanted mean entries per cell (run length seen by phase 2)
+constexpr long long kTargetRun = 128;
+constexpr long long kResidentTiles = 1024;   // phase-2 workgroups resident at once: 256 CUs x 4 (32 wavefronts / 8)
+constexpr int kMaxTileRows = 9984;           // 4 tiles of this height (+ the reduction scratch) fit one CU's 160 KiB   // wanted mean entries per cell (run length seen by phase 2)
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -334,8 +336,8 @@ __device__ __forceinline__ void lds_add(float* slot, float v) {
 
 // Fills the LDS tile with the sums of this tile's rows.  `seed` (may be null) holds the
 // long rows' sums and zeros elsewhere.
-template <int R, int kReduceBlock, int U>
-__device__ __forceinline__ void tile_accumulate(float* tile, int tile_index, int num_strips, int num_rows,
+template <int kReduceBlock, int U>
+__device__ __forceinline__ void tile_accumulate(float* tile, int R, int tile_index, int num_strips, int num_rows,
                                                 const int2* __restrict__ cells_t,
                                                 const float* __restrict__ prod,
                                                 const unsigned short* __restrict__ a_lrow,
@@ -356,12 +358,16 @@ __device__ __forceinline__ void tile_accumulate(float* tile, int tile_index, int
     // A group of kRuns runs is processed together, U chunks of 64 entries from each per pass:
     // all 8 loads of a pass are issued before its first add, and a pass is repeated only while
     // some run of the group still has entries left (U is picked from the mean run length).
-    constexpr int kRuns = 8 / U;
+    constexpr int kSlots = 8;             // (run, chunk) loads in flight per lane (16 measured slower)
+    constexpr int kRuns = kSlots / U;
     const int2* mine = cells_t + static_cast<long long>(tile_index) * num_strips;
+    int2 meta_next = lane < num_strips ? mine[lane] : make_int2(0, 0);
     for (int s0 = 0; s0 < num_strips; s0 += 64) {
         // the tile's next 64 runs: every wavefront loads their (begin, length) (one coalesced
-        // 512-byte load, L1-shared) and takes every kWaves-th group of kRuns runs
-        const int2 meta = s0 + lane < num_strips ? mine[s0 + lane] : make_int2(0, 0);
+        // 512-byte load, L1-shared; fetched one batch ahead so its latency hides behind the
+        // current batch) and takes every kWaves-th group of kRuns runs
+        const int2 meta = meta_next;
+        meta_next = s0 + 64 + lane < num_strips ? mine[s0 + 64 + lane] : make_int2(0, 0);
         const int runs = min(64, num_strips - s0);
         for (int k0 = wave * kRuns; k0 < runs; k0 += kWaves * kRuns) {
             int begin[kRuns], len[kRuns], lead[kRuns];
@@ -385,8 +391,8 @@ __device__ __forceinline__ void tile_accumulate(float* tile, int tile_index, int
                 longest += 1;
             }
             for (int done = 0; done < longest; done += 64 * U) {
-                float p[8];
-                int r[8];
+                float p[kSlots];
+                int r[kSlots];
                 if (U >= 2) {
 #pragma unroll
                     for (int j = 0; j < kRuns; ++j) {
@@ -420,7 +426,7 @@ __device__ __forceinline__ void tile_accumulate(float* tile, int tile_index, int
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < kSlots; ++q) {
                     if (r[q] >= 0) lds_add(&tile[r[q]], p[q]);
                 }
             }
@@ -429,23 +435,24 @@ __device__ __forceinline__ void tile_accumulate(float* tile, int tile_index, int
     __syncthreads();
 }
 
-template <int R, int kReduceBlock, int U>
+// The tile (R floats, R = plan.tile_rows: any multiple of 64) lives in dynamic LDS.
+template <int kReduceBlock, int U>
 __global__ __launch_bounds__(kReduceBlock)
-void tiled_reduce_kernel(const int2* __restrict__ cells_t, int num_strips,
+void tiled_reduce_kernel(int R, const int2* __restrict__ cells_t, int num_strips,
                          const float* __restrict__ prod,
                          const unsigned short* __restrict__ a_lrow,
                          float* __restrict__ seed,
                          int num_rows, float* __restrict__ y) {
-    __shared__ float tile[R];
-    tile_accumulate<R, kReduceBlock, U>(tile, blockIdx.x, num_strips, num_rows, cells_t, prod, a_lrow, seed);
+    extern __shared__ float tile[];
+    tile_accumulate<kReduceBlock, U>(tile, R, blockIdx.x, num_strips, num_rows, cells_t, prod, a_lrow, seed);
     const long long first = static_cast<long long>(blockIdx.x) * R;
     for (int i = threadIdx.x; i < R && first + i < num_rows; i += kReduceBlock) y[first + i] = tile[i];
 }
 
 // phase 2 with the PageRank update fused into the tile write-out (cf. pr_step_kernel)
-template <int R, int kReduceBlock, int U>
+template <int kReduceBlock, int U>
 __global__ __launch_bounds__(kReduceBlock)
-void tiled_pagerank_reduce_kernel(const int2* __restrict__ cells_t, int num_strips,
+void tiled_pagerank_reduce_kernel(int R, const int2* __restrict__ cells_t, int num_strips,
                                   const float* __restrict__ prod,
                                   const unsigned short* __restrict__ a_lrow,
                                   float* __restrict__ seed,
@@ -455,8 +462,8 @@ void tiled_pagerank_reduce_kernel(const int2* __restrict__ cells_t, int num_stri
                                   const PrState* __restrict__ state,
                                   double* __restrict__ block_partials, PushTargets push) {
     if (state->done) return;
-    __shared__ float tile[R];
-    tile_accumulate<R, kReduceBlock, U>(tile, blockIdx.x, num_strips, local_rows, cells_t, prod, a_lrow, seed);
+    extern __shared__ float tile[];
+    tile_accumulate<kReduceBlock, U>(tile, R, blockIdx.x, num_strips, local_rows, cells_t, prod, a_lrow, seed);
 
     const float teleport = __fdiv_rn(1.0f - damping, static_cast<float>(n_global));
     const float dangling_term = __fdiv_rn(__fmul_rn(damping, state->dangling_sum),
@@ -529,13 +536,29 @@ void choose_shape(long long num_rows, long long num_cols, long long nnz, int* st
         if (long_enough || r >= 8192 || tiles_for(2 * r) < 600) break;
         r <<= 1;
     }
+    // Phase 2 keeps kResidentTiles workgroups on the chip at once (4 per CU while a tile is <= ~39 KiB);
+    // tiles all cost the same, so a count just above a multiple of that leaves the chip nearly idle
+    // for a whole extra round (C5 at R = 8192: 1221 tiles = 1.19 rounds).  Stretch the tiles so they
+    // fill whole rounds (R need not be a power of two), or shrink them if stretching would not fit.
+    {
+        const long long tiles = tiles_for(r);
+        const long long rounds = tiles / kResidentTiles;
+        if (rounds >= 1 && tiles % kResidentTiles != 0) {
+            auto snapped = [&](long long rounds_wanted) {
+                const long long per_tile = (num_rows + rounds_wanted * kResidentTiles - 1) / (rounds_wanted * kResidentTiles);
+                return static_cast<int>((per_tile + 63) / 64 * 64);
+            };
+            int stretched = snapped(rounds);
+            r = stretched <= kMaxTileRows ? stretched : snapped(rounds + 1);
+        }
+    }
     if (const char* env = std::getenv("SPMV_TILED_STRIP")) {
         const int v = std::atoi(env);
         if (v == 4096 || v == 8192 || v == 16384 || v == 32768) w = v;
     }
     if (const char* env = std::getenv("SPMV_TILED_TILE")) {
         const int v = std::atoi(env);
-        if (v == 1024 || v == 2048 || v == 4096 || v == 8192) r = v;
+        if (v >= 64 && v <= 15360 && v % 64 == 0) r = v;
     }
     *strip_cols = w;
     *tile_rows = r;
@@ -565,47 +588,45 @@ hipError_t launch_expand(const TiledPlan& plan, const float* d_x, hipStream_t s)
     }
 }
 
-template <int R, int U>
+template <int U>
 hipError_t launch_reduce_as(const TiledPlan& plan, float* d_y, hipStream_t s) {
-    tiled_reduce_kernel<R, 512, U><<<plan.num_tiles, 512, 0, s>>>(
-        reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_lrow, plan.seed,
-        plan.num_rows, d_y);
+    tiled_reduce_kernel<512, U><<<plan.num_tiles, 512, plan.tile_rows * sizeof(float), s>>>(
+        plan.tile_rows, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_lrow,
+        plan.seed, plan.num_rows, d_y);
     return hipGetLastError();
 }
 
-template <int R>
 hipError_t launch_reduce(const TiledPlan& plan, float* d_y, hipStream_t s) {
     switch (plan.run_chunks) {
-        case 1:  return launch_reduce_as<R, 1>(plan, d_y, s);
-        case 2:  return launch_reduce_as<R, 2>(plan, d_y, s);
-        default: return launch_reduce_as<R, 4>(plan, d_y, s);
+        case 1:  return launch_reduce_as<1>(plan, d_y, s);
+        case 2:  return launch_reduce_as<2>(plan, d_y, s);
+        default: return launch_reduce_as<4>(plan, d_y, s);
     }
 }
 
-template <int R, int U>
+template <int U>
 hipError_t launch_pagerank_reduce_as(const TiledPlan& plan, int row_offset, int n_global, const float* d_r_old,
                                      float* d_r_new, const unsigned char* d_dangling, float damping,
                                      const PrState* d_state, double* d_block_partials,
                                      const PushTargets& push, hipStream_t s) {
-    tiled_pagerank_reduce_kernel<R, 512, U><<<plan.num_tiles, 512, 0, s>>>(
-        reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_lrow, plan.seed,
-        plan.num_rows, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state, d_block_partials,
-        push);
+    tiled_pagerank_reduce_kernel<512, U><<<plan.num_tiles, 512, plan.tile_rows * sizeof(float), s>>>(
+        plan.tile_rows, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_lrow,
+        plan.seed, plan.num_rows, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
+        d_block_partials, push);
     return hipGetLastError();
 }
 
-template <int R>
 hipError_t launch_pagerank_reduce(const TiledPlan& plan, int row_offset, int n_global, const float* d_r_old,
                                   float* d_r_new, const unsigned char* d_dangling, float damping,
                                   const PrState* d_state, double* d_block_partials,
                                   const PushTargets& push, hipStream_t s) {
     switch (plan.run_chunks) {
-        case 1:  return launch_pagerank_reduce_as<R, 1>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                        damping, d_state, d_block_partials, push, s);
-        case 2:  return launch_pagerank_reduce_as<R, 2>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                        damping, d_state, d_block_partials, push, s);
-        default: return launch_pagerank_reduce_as<R, 4>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                        damping, d_state, d_block_partials, push, s);
+        case 1:  return launch_pagerank_reduce_as<1>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
+                                                     damping, d_state, d_block_partials, push, s);
+        case 2:  return launch_pagerank_reduce_as<2>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
+                                                     damping, d_state, d_block_partials, push, s);
+        default: return launch_pagerank_reduce_as<4>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
+                                                     damping, d_state, d_block_partials, push, s);
     }
 }
 
@@ -888,12 +909,7 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
 hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipStream_t s) {
     const hipError_t e = launch_expand(plan, d_x, s);       // phase 1 + the long rows
     if (e != hipSuccess) return e;
-    switch (plan.tile_rows) {
-        case 1024: return launch_reduce<1024>(plan, d_y, s);
-        case 2048: return launch_reduce<2048>(plan, d_y, s);
-        case 4096: return launch_reduce<4096>(plan, d_y, s);
-        default:   return launch_reduce<8192>(plan, d_y, s);
-    }
+    return launch_reduce(plan, d_y, s);
 }
 
 hipError_t tiled_pagerank_step(const TiledPlan& plan, int row_offset, int n_global,
@@ -905,16 +921,8 @@ hipError_t tiled_pagerank_step(const TiledPlan& plan, int row_offset, int n_glob
     // then only rewrite scratch (product stream, seed vector), which nothing reads.
     const hipError_t e = launch_expand(plan, d_r_old, s);   // phase 1 + the long rows
     if (e != hipSuccess) return e;
-    switch (plan.tile_rows) {
-        case 1024: return launch_pagerank_reduce<1024>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                       damping, d_state, d_block_partials, push, s);
-        case 2048: return launch_pagerank_reduce<2048>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                       damping, d_state, d_block_partials, push, s);
-        case 4096: return launch_pagerank_reduce<4096>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                       damping, d_state, d_block_partials, push, s);
-        default:   return launch_pagerank_reduce<8192>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                       damping, d_state, d_block_partials, push, s);
-    }
+    return launch_pagerank_reduce(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
+                                  d_block_partials, push, s);
 }
 
 } // namespace detail

@@ -288,8 +288,9 @@ def test_tiled_engine_shape_rules(spmv):
     """Host logic of the LDS-tiled engine (csrc/tiled.hip choose_shape / eligibility), no GPU needed:
     which matrices it takes, and that strips / tiles stay inside the LDS budgets and index widths."""
     takes, w, r = spmv.tiled_shape(10_000_000, 10_000_000, 160_000_000)          # BASELINE config 5
-    assert takes and w in (4096, 8192, 16384, 32768) and r in (1024, 2048, 4096, 8192)
-    assert (10_000_000 + r - 1) // r >= 1024                                       # enough row tiles to fill the chip
+    assert takes and w in (4096, 8192, 16384, 32768) and r % 64 == 0 and 1024 <= r <= 9984
+    tiles = (10_000_000 + r - 1) // r
+    assert 1000 <= tiles <= 1024                                                   # one full round of resident tiles, no tail
     assert 160_000_000 / (((10_000_000 + w - 1) // w) * ((10_000_000 + r - 1) // r)) >= 100   # long enough runs
     takes, w, r = spmv.tiled_shape(1_250_000, 10_000_032, 20_000_000)              # a 1/8 row shard of it
     assert takes and w == 32768 and (1_250_000 + r - 1) // r >= 600
@@ -303,4 +304,6 @@ def test_tiled_engine_shape_rules(spmv):
         rows, cols = int(rng.integers(1, 50_000_000)), int(rng.integers(1, 50_000_000))
         nnz = int(rng.integers(1, 2_000_000_000))
         takes, w, r = spmv.tiled_shape(rows, cols, nnz)
-        assert w in (4096, 8192, 16384, 32768) and r in (1024, 2048, 4096, 8192)   # u16 local indices, LDS fits
+        assert w in (4096, 8192, 16384, 32768) and r % 64 == 0 and 1024 <= r <= 9984   # u16 local indices, LDS fits
+        tiles = (rows + r - 1) // r
+        assert tiles < 1024 or tiles % 1024 == 0 or tiles % 1024 > 900               # whole rounds of resident tiles

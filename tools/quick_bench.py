@@ -45,6 +45,10 @@ def main():
         A = wl.uniform_csr_device(42, 1_250_000, 10_000_000, 16); report("c5 shard 1/8", A, kernels=(11, 1)); A.close()
     if "shard2" in which:
         A = wl.uniform_csr_device(42, 5_000_000, 10_000_000, 16); report("c5 shard 1/2", A, kernels=(11,)); A.close()
+    if "c2only" in which:
+        A = wl.uniform_csr_device(42, 1_000_000, 1_000_000, 16); report("c2 1M x 16", A, kernels=(11,)); A.close()
+    if "c4only" in which:
+        A = wl.power_law_csr_device(42, 1_000_000, 1_000_000); report("c4 1M power-law", A, kernels=(12,)); A.close()
     if "c5only" in which:
         A = wl.uniform_csr_device(42, 10_000_000, 10_000_000, 16); report("c5 10M x 16", A, kernels=(11,)); A.close()
     if "c5" in which:

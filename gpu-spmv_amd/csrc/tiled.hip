@@ -202,6 +202,21 @@ void cell_table_kernel(const int* __restrict__ offs, int num_strips, int num_til
     }
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each XCD has its
+// own L2).  Both phases hand every XCD a CONTIGUOUS range of the work list, walked in order:
+// neighbours in the list then run on one XCD at about the same time and share what they both
+// touch through its L2 — the x strip of consecutive phase-1 items, the 128-byte lines that
+// adjacent runs of neighbouring tiles straddle in phase 2.  Returns -1 for the padding blocks of a
+// grid rounded up to a multiple of 8.  (Speed only: correctness never depends on placement.
+// Measured against the plain order on one box: C2 59.1 -> 55.0 us, C5 535.5 -> 530.1 us, 1/8 shard 84.5 -> 85.2 us.)
+constexpr int kXcds = 8;
+__device__ __forceinline__ int xcd_contiguous(int block, int count) {
+    const int per_xcd = (count + kXcds - 1) / kXcds;
+    const int which = (block % kXcds) * per_xcd + block / kXcds;
+    return block / kXcds < per_xcd && which < count ? which : -1;
+}
+__host__ inline int xcd_grid(int count) { return (count + kXcds - 1) / kXcds * kXcds; }
+
 // ------------------------------------------------------------------------ phase 1 ----
 // Rows too long for the cells are cut into chunks of kLongChunk entries; one wavefront per
 // chunk sums it by direct gather and adds the sum atomically into seed[row].  seed is zero on
@@ -229,7 +244,7 @@ __device__ __forceinline__ void long_row_chunk(const LongRows& lr, int which, co
 // as w_j * x_j and an entry's product is a plain LDS read (the same rounded product as a_ij * x_j).
 template <int W, int kExpandBlock, bool FOLD>
 __global__ __launch_bounds__(kExpandBlock)
-void tiled_expand_kernel(const int* __restrict__ items, int long_blocks,
+void tiled_expand_kernel(const int* __restrict__ items, int num_items, int long_blocks,
                          const float* __restrict__ a_val,
                          const unsigned short* __restrict__ a_lcol,
                          const float* __restrict__ col_weight,
@@ -241,7 +256,8 @@ void tiled_expand_kernel(const int* __restrict__ items, int long_blocks,
         return;
     }
     __shared__ float xs[W];
-    const int item = blockIdx.x - long_blocks;
+    const int item = xcd_contiguous(blockIdx.x - long_blocks, num_items);     // long_blocks is a multiple of 8
+    if (item < 0) return;
     const int strip = items[3 * item];
     const int begin = items[3 * item + 1];
     const int end = items[3 * item + 2];
@@ -438,21 +454,23 @@ __device__ __forceinline__ void tile_accumulate(float* tile, int R, int tile_ind
 // The tile (R floats, R = plan.tile_rows: any multiple of 64) lives in dynamic LDS.
 template <int kReduceBlock, int U>
 __global__ __launch_bounds__(kReduceBlock)
-void tiled_reduce_kernel(int R, const int2* __restrict__ cells_t, int num_strips,
+void tiled_reduce_kernel(int R, int num_tiles, const int2* __restrict__ cells_t, int num_strips,
                          const float* __restrict__ prod,
                          const unsigned short* __restrict__ a_lrow,
                          float* __restrict__ seed,
                          int num_rows, float* __restrict__ y) {
     extern __shared__ float tile[];
-    tile_accumulate<kReduceBlock, U>(tile, R, blockIdx.x, num_strips, num_rows, cells_t, prod, a_lrow, seed);
-    const long long first = static_cast<long long>(blockIdx.x) * R;
+    const int tile_index = xcd_contiguous(blockIdx.x, num_tiles);
+    if (tile_index < 0) return;
+    tile_accumulate<kReduceBlock, U>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_lrow, seed);
+    const long long first = static_cast<long long>(tile_index) * R;
     for (int i = threadIdx.x; i < R && first + i < num_rows; i += kReduceBlock) y[first + i] = tile[i];
 }
 
 // phase 2 with the PageRank update fused into the tile write-out (cf. pr_step_kernel)
 template <int kReduceBlock, int U>
 __global__ __launch_bounds__(kReduceBlock)
-void tiled_pagerank_reduce_kernel(int R, const int2* __restrict__ cells_t, int num_strips,
+void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__ cells_t, int num_strips,
                                   const float* __restrict__ prod,
                                   const unsigned short* __restrict__ a_lrow,
                                   float* __restrict__ seed,
@@ -463,13 +481,15 @@ void tiled_pagerank_reduce_kernel(int R, const int2* __restrict__ cells_t, int n
                                   double* __restrict__ block_partials, PushTargets push) {
     if (state->done) return;
     extern __shared__ float tile[];
-    tile_accumulate<kReduceBlock, U>(tile, R, blockIdx.x, num_strips, local_rows, cells_t, prod, a_lrow, seed);
+    const int tile_index = xcd_contiguous(blockIdx.x, num_tiles);
+    if (tile_index < 0) return;
+    tile_accumulate<kReduceBlock, U>(tile, R, tile_index, num_strips, local_rows, cells_t, prod, a_lrow, seed);
 
     const float teleport = __fdiv_rn(1.0f - damping, static_cast<float>(n_global));
     const float dangling_term = __fdiv_rn(__fmul_rn(damping, state->dangling_sum),
                                           static_cast<float>(n_global));
     double res2 = 0.0, mass = 0.0;
-    const long long first = static_cast<long long>(blockIdx.x) * R;
+    const long long first = static_cast<long long>(tile_index) * R;
     for (int i = threadIdx.x; i < R && first + i < local_rows; i += kReduceBlock) {
         const long long node = row_offset + first + i;
         const float fresh = __fadd_rn(__fadd_rn(__fmul_rn(damping, tile[i]), dangling_term), teleport);
@@ -481,8 +501,8 @@ void tiled_pagerank_reduce_kernel(int R, const int2* __restrict__ cells_t, int n
     }
     block_sum2<kReduceBlock>(res2, mass);
     if (threadIdx.x == 0) {
-        block_partials[2 * blockIdx.x] = res2;
-        block_partials[2 * blockIdx.x + 1] = mass;
+        block_partials[2 * tile_index] = res2;
+        block_partials[2 * tile_index + 1] = mass;
     }
 }
 
@@ -567,13 +587,14 @@ void choose_shape(long long num_rows, long long num_cols, long long nnz, int* st
 template <int W, int BLOCK>
 hipError_t launch_expand_as(const TiledPlan& plan, const float* d_x, hipStream_t s) {
     const LongRows lr{plan.long_chunks, plan.num_long_chunks, plan.csr_nnz, plan.csr_cols, plan.csr_vals, plan.seed};
-    const int long_blocks = (plan.num_long_chunks + BLOCK / 64 - 1) / (BLOCK / 64);
+    const int long_blocks = xcd_grid((plan.num_long_chunks + BLOCK / 64 - 1) / (BLOCK / 64));
+    const int grid = long_blocks + xcd_grid(plan.num_items);
     if (plan.col_weight) {
-        tiled_expand_kernel<W, BLOCK, true><<<plan.num_items + long_blocks, BLOCK, 0, s>>>(
-            plan.items, long_blocks, nullptr, plan.a_lcol, plan.col_weight, d_x, plan.num_cols, plan.prod, lr);
+        tiled_expand_kernel<W, BLOCK, true><<<grid, BLOCK, 0, s>>>(
+            plan.items, plan.num_items, long_blocks, nullptr, plan.a_lcol, plan.col_weight, d_x, plan.num_cols, plan.prod, lr);
     } else {
-        tiled_expand_kernel<W, BLOCK, false><<<plan.num_items + long_blocks, BLOCK, 0, s>>>(
-            plan.items, long_blocks, plan.a_val, plan.a_lcol, nullptr, d_x, plan.num_cols, plan.prod, lr);
+        tiled_expand_kernel<W, BLOCK, false><<<grid, BLOCK, 0, s>>>(
+            plan.items, plan.num_items, long_blocks, plan.a_val, plan.a_lcol, nullptr, d_x, plan.num_cols, plan.prod, lr);
     }
     return hipGetLastError();
 }
@@ -590,8 +611,8 @@ hipError_t launch_expand(const TiledPlan& plan, const float* d_x, hipStream_t s)
 
 template <int U>
 hipError_t launch_reduce_as(const TiledPlan& plan, float* d_y, hipStream_t s) {
-    tiled_reduce_kernel<512, U><<<plan.num_tiles, 512, plan.tile_rows * sizeof(float), s>>>(
-        plan.tile_rows, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_lrow,
+    tiled_reduce_kernel<512, U><<<xcd_grid(plan.num_tiles), 512, plan.tile_rows * sizeof(float), s>>>(
+        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_lrow,
         plan.seed, plan.num_rows, d_y);
     return hipGetLastError();
 }
@@ -609,8 +630,8 @@ hipError_t launch_pagerank_reduce_as(const TiledPlan& plan, int row_offset, int 
                                      float* d_r_new, const unsigned char* d_dangling, float damping,
                                      const PrState* d_state, double* d_block_partials,
                                      const PushTargets& push, hipStream_t s) {
-    tiled_pagerank_reduce_kernel<512, U><<<plan.num_tiles, 512, plan.tile_rows * sizeof(float), s>>>(
-        plan.tile_rows, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_lrow,
+    tiled_pagerank_reduce_kernel<512, U><<<xcd_grid(plan.num_tiles), 512, plan.tile_rows * sizeof(float), s>>>(
+        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_lrow,
         plan.seed, plan.num_rows, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
         d_block_partials, push);
     return hipGetLastError();

@@ -26,7 +26,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace spmv {
@@ -200,6 +203,36 @@ void pr_mask_kernel(const float* __restrict__ col_sums, int n, unsigned char* __
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
 }
 
+// ---- final renormalisation r /= sum(r) on the device: block partial sums in double, then every
+// block folds the partials in the same fixed order and scales its share (IEEE division) ----
+__global__ __launch_bounds__(kBlock)
+void pr_vector_sum_kernel(const float* __restrict__ v, size_t n, double* __restrict__ block_out) {
+    double acc = 0.0, unused = 0.0;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        acc += static_cast<double>(v[i]);
+    }
+    block_sum2<kBlock>(acc, unused);
+    if (threadIdx.x == 0) block_out[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(kBlock)
+void pr_scale_kernel(float* __restrict__ v, size_t n, const double* __restrict__ block_sums, int blocks) {
+    __shared__ float s_total;
+    if (threadIdx.x == 0) {
+        double total = 0.0;
+        for (int b = 0; b < blocks; ++b) total += block_sums[b];
+        s_total = static_cast<float>(total);
+    }
+    __syncthreads();
+    const float total = s_total;
+    if (!(total > 0.0f)) return;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        v[i] = __fdiv_rn(v[i], total);
+    }
+}
+
 // ---- top-k by radix select on the float bit patterns (non-negative ranks order like uints) ----
 // pass A: histogram of the high 16 bits; pass B: histogram of the low 16 bits of the values
 // whose high half equals `prefix`; pass C: gather everything above the threshold plus as many
@@ -329,6 +362,16 @@ hipError_t pr_mask_from_column_sums(const float* d_col_sums, int n, unsigned cha
     return hipGetLastError();
 }
 
+// v /= sum(v), the sum accumulated in double; d_scratch holds >= kNormaliseBlocks doubles
+constexpr int kNormaliseBlocks = 1024;
+hipError_t pr_normalise(float* d_v, size_t n, double* d_scratch, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const int blocks = static_cast<int>(std::min<size_t>(kNormaliseBlocks, (n + kBlock - 1) / kBlock));
+    pr_vector_sum_kernel<<<blocks, kBlock, 0, s>>>(d_v, n, d_scratch);
+    pr_scale_kernel<<<blocks, kBlock, 0, s>>>(d_v, n, d_scratch, blocks);
+    return hipGetLastError();
+}
+
 } // namespace detail
 
 // ---------------------------------------------------------------------------
@@ -361,6 +404,22 @@ struct DeviceArray {
     }
 };
 
+// SPMV_TRACE=1: wall-clock time of each host phase of a call, on stderr
+struct Trace {
+    const char* what;
+    bool on;
+    mutable std::chrono::steady_clock::time_point last;
+    explicit Trace(const char* name) : what(name), on(std::getenv("SPMV_TRACE") != nullptr),
+                                       last(std::chrono::steady_clock::now()) {}
+    void mark(const char* phase) const {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[spmv trace] %s: %-22s %9.3f ms\n", what, phase,
+                     std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
 } // namespace
 
 PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
@@ -373,8 +432,13 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     const int n = adj->num_rows;
     result.ranks = new float[std::max(n, 0)];
     const float start = n > 0 ? 1.0f / n : 0.0f;
-    std::fill_n(result.ranks, std::max(n, 0), start);
     if (n <= 0) return result;
+    // every exit that does not deliver computed ranks hands back the start vector (filled on the way
+    // out, so the successful path does not pay a 4n-byte host pass)
+    struct StartVector {
+        float* ranks; int n; float value; bool armed;
+        ~StartVector() { if (armed) std::fill_n(ranks, n, value); }
+    } start_vector{result.ranks, n, start, true};
 
     // The matrix must be resident on the device (csr_to_gpu), like the reference's
     // spmv_csr call requires; otherwise the loop ends at once with the start vector.
@@ -399,14 +463,28 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
         return result;
     }
 
+    const Trace trace("pagerank");
     bool ok = hipMemsetAsync(mask.ptr, 0, len, stream) == hipSuccess
            && hipMemsetAsync(dangling_count.ptr, 0, sizeof(unsigned long long), stream) == hipSuccess
            && detail::pr_fill(r_a.ptr, len, start, stream) == hipSuccess
            && detail::pr_fill(r_b.ptr, len, start, stream) == hipSuccess;
 
-    // dangling mask: host scan when host arrays exist (reference semantics), else on device
+    // large x: the steps run through the LDS-tiled engine (plan cached with the matrix)
+    const detail::TiledPlan* plan = ok ? detail::tiled_plan_for(adj, stream) : nullptr;
+    trace.mark("buffers + plan");
+
+    // Dangling mask.  A plan with folded values knows every column's one stored value w (0 where the
+    // column has no entry): the reference's sequential fp32 column sum of k copies of w is 0 exactly
+    // when w == 0, so the mask is read off the weights.  Otherwise: host scan when host arrays exist
+    // (reference semantics), else atomic column sums on the device.
     unsigned long long num_dangling = 0;
-    if (ok && adj->values && adj->col_indices && adj->row_ptrs) {
+    if (ok && plan && plan->col_weight) {
+        ok = detail::pr_mask_from_column_sums(plan->col_weight, std::min(n, adj->num_cols), mask.ptr,
+                                              dangling_count.ptr, stream) == hipSuccess
+          && hipMemcpyAsync(&num_dangling, dangling_count.ptr, sizeof(num_dangling),
+                            hipMemcpyDeviceToHost, stream) == hipSuccess
+          && hipStreamSynchronize(stream) == hipSuccess;
+    } else if (ok && adj->values && adj->col_indices && adj->row_ptrs) {
         const std::vector<unsigned char> host_mask = dangling_mask_host(adj);
         const size_t m = std::min(host_mask.size(), static_cast<size_t>(n));
         for (size_t c = 0; c < m; ++c) num_dangling += host_mask[c];
@@ -424,6 +502,7 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
           && hipStreamSynchronize(stream) == hipSuccess;
     }
     if (!ok) return result;
+    trace.mark("dangling mask");
 
     // dangling mass of the start vector: the same left-to-right fp32 sum as the host loop
     PrState host_state{};
@@ -440,9 +519,8 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     shard.d_vals = adj->d_values;
     shard.d_dangling = mask.ptr;
     shard.d_state = state.ptr;
-    // large x: run the steps through the LDS-tiled engine (plan cached with the matrix)
-    const int partial_pairs = detail::pr_shard_prepare(&shard, detail::tiled_plan_for(adj, stream));
-    ok = ok && partials.alloc(2 * static_cast<size_t>(partial_pairs)) == hipSuccess;
+    const int partial_pairs = detail::pr_shard_prepare(&shard, plan);
+    ok = ok && partials.alloc(std::max<size_t>(2 * static_cast<size_t>(partial_pairs), detail::kNormaliseBlocks)) == hipSuccess;
     shard.d_block_partials = partials.ptr;
 
     // Pinned mirrors of the device state, two deep: the host enqueues step k+1
@@ -472,30 +550,24 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
         ok = hipMemcpyAsync(&host_state, state.ptr, sizeof(PrState), hipMemcpyDeviceToHost, stream) == hipSuccess
           && hipStreamSynchronize(stream) == hipSuccess;
     }
+    trace.mark("iterations");
     if (ok) {
         result.iterations = host_state.iterations;
         result.final_residual = host_state.final_residual;
         result.converged = host_state.converged != 0;
-        // the last written vector: step k (0-based) writes bufs[(k + 1) & 1]
-        const float* last = bufs[host_state.iterations & 1];
-        ok = hipMemcpy(result.ranks, last, static_cast<size_t>(n) * sizeof(float),
-                       hipMemcpyDeviceToHost) == hipSuccess;
+        // the last written vector: step k (0-based) writes bufs[(k + 1) & 1].
+        // Final renormalisation on the device before the copy: r /= sum(r), the sum accumulated in
+        // double (the reference's fp32 running sum loses digits at n ~ 1e7).
+        float* last = bufs[host_state.iterations & 1];
+        ok = detail::pr_normalise(last, static_cast<size_t>(n), partials.ptr, stream) == hipSuccess
+          && hipMemcpyAsync(result.ranks, last, static_cast<size_t>(n) * sizeof(float),
+                            hipMemcpyDeviceToHost, stream) == hipSuccess
+          && hipStreamSynchronize(stream) == hipSuccess;
     }
+    trace.mark("normalise + copy out");
     if (pinned) (void)hipHostFree(pinned);
     for (hipEvent_t e : seen) if (e) (void)hipEventDestroy(e);
-    if (!ok) {
-        std::fill_n(result.ranks, n, start);
-        return result;
-    }
-
-    // final renormalisation (sum accumulated in double; the reference's fp32
-    // running sum loses digits at n ~ 1e7)
-    double total = 0.0;
-    for (int i = 0; i < n; ++i) total += result.ranks[i];
-    const float total_f = static_cast<float>(total);
-    if (total_f > 0.0f) {
-        for (int i = 0; i < n; ++i) result.ranks[i] /= total_f;
-    }
+    start_vector.armed = !ok;
     return result;
 }
 

@@ -377,6 +377,32 @@ def test_ell_through_the_tiled_engine(gpu, oracle):
     gpu.ell_destroy(E)
 
 
+def test_ell_with_column_uniform_values_through_the_tiled_engine(gpu, oracle):
+    """An ELL adjacency matrix (all stored values 1/outdeg of their column): the plan built from the slabs
+    folds the values (padding slots are skipped by the probe) and still matches the oracle."""
+    import ctypes
+    rows, cols, k = 300_000, 400_000, 10
+    rng = np.random.default_rng(11)
+    lens = rng.integers(1, k + 1, size=rows)
+    rp, ci, _ = gpu.synth.stratified_csr(12, 0, lens, cols)
+    outdeg = np.bincount(ci, minlength=cols)
+    va = (np.float32(1.0) / np.maximum(outdeg, 1).astype(np.float32))[ci]
+    kk, ecols, evals = oracle.ell_from_csr(rp, ci, va)
+    x = np.abs(gpu.synth.vector(12, 1, cols)) + np.float32(0.01)
+    want = oracle.spmv_ell(rows, kk, ecols, evals, x)
+    E = gpu.ell_create(rows, cols, kk)
+    ctypes.memmove(E.contents.col_indices, ecols.ctypes.data, ecols.nbytes)
+    ctypes.memmove(E.contents.values, evals.ctypes.data, evals.nbytes)
+    assert gpu.ell_to_gpu(E) == 0
+    d_x, d_y = gpu.CudaBuffer(cols), gpu.CudaBuffer(rows)
+    d_x.copyFromHost(x, cols)
+    cfg = gpu.SpMVConfig(kernel_type=gpu.SpMVConfig.ELL_KERNEL, use_texture=True)
+    for _ in range(2):
+        assert gpu.spmv_ell(E, d_x, d_y, cfg, cols).error_code == 0
+    assert max_rel_err(want, d_y.copyToHost(rows)) <= REORDER_TOL
+    gpu.ell_destroy(E)
+
+
 # ------------------------------------------------ BASELINE configs 3, 4, 5 at full size --------
 def _device_inputs(gpu, A, cols, tag):
     wl = __import__("importlib").import_module("gpu-spmv_amd.workloads")

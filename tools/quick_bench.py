@@ -49,6 +49,17 @@ def main():
         A = wl.uniform_csr_device(42, 1_000_000, 1_000_000, 16); report("c2 1M x 16", A, kernels=(11,)); A.close()
     if "c4only" in which:
         A = wl.power_law_csr_device(42, 1_000_000, 1_000_000); report("c4 1M power-law", A, kernels=(12,)); A.close()
+    if "pagerank" in which:   # the drop-in pagerank() call end to end on the column-stochastic C5 (SPMV_TRACE=1 for phases)
+        import time
+        A = wl.uniform_csr_device(42, 10_000_000, 10_000_000, 16)
+        counts = wl.make_column_stochastic(A)
+        for attempt in range(3):
+            t0 = time.perf_counter()
+            res = spmv.pagerank(A.handle, spmv.PageRankConfig(0.85, 1e-6, 100))
+            dt = time.perf_counter() - t0
+            print(f"pagerank() call {attempt}: {dt*1e3:.2f} ms, {res.iterations} iterations, converged={res.converged}, "
+                  f"sum={float(res.ranks.sum(dtype=np.float64)):.9f}", flush=True)
+        counts.release(); A.close()
     if "c5only" in which:
         A = wl.uniform_csr_device(42, 10_000_000, 10_000_000, 16); report("c5 10M x 16", A, kernels=(11,)); A.close()
     if "c5" in which:

@@ -896,18 +896,22 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return cleanup(e);
 
-    // phase-1 work items: every strip's range cut into pieces of <= item_entries (enough
+    // phase-1 work items: every strip's range cut into EQUAL pieces of <= item_entries (enough
     // pieces to fill the chip several times), piece boundaries on multiples of 4 entries
     const long long floor_entries = std::max<long long>(kMinItemEntries, plan->strip_cols);   // strip load <= 40 % of the stream
-    const int item_entries = static_cast<int>(std::min<long long>(
+    int item_entries = static_cast<int>(std::min<long long>(
         kMaxItemEntries, std::max<long long>(floor_entries, (plan->nnz / 2048 + 3) / 4 * 4)));
+    if (const char* env = std::getenv("SPMV_TILED_ITEM")) item_entries = std::max(1024, std::atoi(env));
     std::vector<int> items;
     for (int strip = 0; strip < plan->num_strips; ++strip) {
-        int b = host_strip[strip];
-        const int stop = host_strip[strip + 1];
-        while (b < stop) {
-            int next = std::min(stop, ((b + item_entries) / 4) * 4);
-            if (next <= b) next = stop;
+        const int begin = host_strip[strip], stop = host_strip[strip + 1];
+        const int parts = (stop - begin + item_entries - 1) / item_entries;
+        int b = begin;
+        for (int part = 1; part <= parts; ++part) {
+            int next = part == parts ? stop
+                                     : static_cast<int>(begin + static_cast<long long>(stop - begin) * part / parts) / 4 * 4;
+            next = std::max(next, b);
+            if (next == b && part != parts) continue;
             items.push_back(strip);
             items.push_back(b);
             items.push_back(next);

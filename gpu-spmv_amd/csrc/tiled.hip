@@ -16,13 +16,17 @@
 //        matrix = 16 .. 128 KiB) into LDS, streams its share of the strip's entries (value, local column) with
 //        16-byte loads, gathers x from LDS and stores the products — same order, so
 //        loads and stores are all contiguous.
-//   phase 2 "reduce" : a workgroup owns one row tile (R = 1 K .. 8 K rows = 4 .. 32 KiB of LDS).
+//   phase 2 "reduce" : a workgroup owns one row tile (R rows in dynamic LDS, R a multiple of 64
+//        up to 9984 = 39 KiB, stretched so that the tiles fill whole rounds of resident workgroups).
 //        The tile's entries are one contiguous run per strip (cell table); the waves
 //        walk the runs, add each product into the LDS tile and finally write the tile
 //        out with coalesced stores (optionally through the fused PageRank update).
 //        gfx950's ds_add_f32 is ~30x slower than its integer LDS atomics (0.38 vs 11.7
 //        lanes/clk/CU measured), so the add is a compare-and-swap on the word's integer
 //        image (3.5 lanes/clk/CU measured; race-free for any row multiplicity).
+//   folding : when every stored entry of a column has the same bits, the value stream is dropped
+//        and phase 1 gathers w_j * x_j from LDS (column_weight_probe_kernel, FOLD instantiation).
+//   both phases walk their work lists in per-XCD contiguous slices (xcd_contiguous).
 //   long rows (more than min(1024, 2 x strips) entries) would make many lanes fight over one
 //        LDS word; they are left out of the cells and summed in 512-entry chunks by extra
 //        wavefronts of the phase-1 grid (direct gather) into a side vector that seeds the tiles.
@@ -51,17 +55,17 @@ namespace {
 using namespace dev;
 
 // W (x columns per LDS strip) and R (y rows per LDS tile) are chosen per matrix
-// (choose_shape below) from these instantiations:
-//   W in {4096, 8192, 16384, 32768} = 16 .. 128 KiB of LDS in phase 1
-//   R in {1024, 2048, 4096, 8192} = 4 .. 32 KiB of LDS in phase 2
+// (choose_shape below):
+//   W in {4096, 8192, 16384, 32768} = 16 .. 128 KiB of static LDS in phase 1 (template instantiations)
+//   R = any multiple of 64 in [64, kMaxTileRows]: dynamic LDS in phase 2
 constexpr int kMaxItemEntries = 65536;   // phase-1 work item size bounds (entries)
 constexpr int kMinItemEntries = 4096;
 constexpr int kMaxLongRow = 1024;     // rows longer than min(this, 2 * strips) bypass the cells
 constexpr int kLongChunk = 512;       // entries per wavefront of the long-row path
 constexpr long long kMaxCells = 1LL << 26;
-constexpr long long kTargetRun = 128;
+constexpr long long kTargetRun = 128;        // wanted mean entries per cell (run length seen by phase 2)
 constexpr long long kResidentTiles = 1024;   // phase-2 workgroups resident at once: 256 CUs x 4 (32 wavefronts / 8)
-constexpr int kMaxTileRows = 9984;           // 4 tiles of this height (+ the reduction scratch) fit one CU's 160 KiB   // wanted mean entries per cell (run length seen by phase 2)
+constexpr int kMaxTileRows = 9984;           // 4 tiles of this height (+ the reduction scratch) fit one CU's 160 KiB
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

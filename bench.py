@@ -263,10 +263,16 @@ def main():
         torch.cuda.synchronize()
         t_f = (time.perf_counter() - t0) / args.steps
         info_f = spmv.csr_tiled_info(folded._A)
+        folded_traffic = None
+        try:
+            folded_traffic = json.load(open(pmc_file)).get("folded", {}).get("bytes_per_step")
+        except Exception:
+            pass
         result["pagerank_step_values_folded"] = {
             "ms_per_step": round(t_f * 1e3, 4), "effective_gb_s": round(bytes_per_step / t_f / 1e9, 1),
             "frac_of_hbm_peak": round(bytes_per_step / t_f / 1e9 / HBM_PEAK_GBS, 4),
             "values_folded": bool(info_f and info_f.get("values_folded")),
+            "traffic": folded_traffic,
             "note": "same matrix, same arithmetic (w_j * x_j rounded once per column); applies only when every "
                     "stored entry of a column is bit-identical"}
         folded.close()

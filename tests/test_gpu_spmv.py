@@ -306,10 +306,13 @@ def test_tiled_engine_folds_column_uniform_values(gpu, oracle, monkeypatch):
     rows = cols = 400_000
     lens = gpu.synth.power_law_lengths(9, rows, max_len=20000, n_cols=cols)       # long rows keep their CSR values
     rp, ci, _ = gpu.synth.stratified_csr(9, 0, lens, cols)
+    ci = np.where(ci == 70_000, 70_001, ci).astype(np.int32)                      # column 70000 has no entry at all
     outdeg = np.bincount(ci, minlength=cols)
     va = (np.float32(1.0) / np.maximum(outdeg, 1).astype(np.float32))[ci]
     x = np.abs(gpu.synth.vector(9, 1, cols)) + np.float32(0.01)
+    x[70_000] = np.inf                                                            # 0 * inf must not leak out of the unused column
     want = oracle.spmv_csr(rp, ci, va, x)
+    assert np.isfinite(want).all()
 
     got, info = _tiled_with_info(gpu, rp, ci, va, cols, x)
     assert info["values_folded"] and info["long_rows"] > 0

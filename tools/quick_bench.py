@@ -60,6 +60,17 @@ def main():
             print(f"pagerank() call {attempt}: {dt*1e3:.2f} ms, {res.iterations} iterations, converged={res.converged}, "
                   f"sum={float(res.ranks.sum(dtype=np.float64)):.9f}", flush=True)
         counts.release(); A.close()
+    if "pr_small" in which:   # launch-bound PageRank: small graphs, 100 iterations forced (tolerance 0)
+        import time
+        for n, k in ((10_000, 8), (100_000, 8), (1_000_000, 8)):
+            A = wl.uniform_csr_device(7, n, n, k)
+            counts = wl.make_column_stochastic(A)
+            for attempt in range(3):
+                t0 = time.perf_counter()
+                res = spmv.pagerank(A.handle, spmv.PageRankConfig(0.85, 0.0, 100))
+                dt = time.perf_counter() - t0
+            print(f"pagerank() n={n} k={k}: {dt*1e3:.2f} ms for {res.iterations} iterations = {dt*1e6/max(res.iterations,1):.1f} us/iteration", flush=True)
+            counts.release(); A.close()
     if "c5only" in which:
         A = wl.uniform_csr_device(42, 10_000_000, 10_000_000, 16); report("c5 10M x 16", A, kernels=(11,)); A.close()
     if "c5" in which:

@@ -809,7 +809,9 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     plan->num_long = totals[1];
     {   // 64-entry chunks taken from a run per pass of phase 2: cover the mean run with some slack
         const long long mean_run = plan->nnz / std::max<long long>(cells, 1);
-        plan->run_chunks = mean_run <= 48 ? 1 : (mean_run <= 384 ? 2 : 4);
+        // same-box A/B with the paired loads: 4 chunks win from ~130-entry runs on (C2 133: 54.7 -> 54.2 us,
+        // C4 168: 55.8 -> 54.4, C5 256: 532 -> 521), 2 chunks below (1/8 shard, 107: 84 vs 86.5)
+        plan->run_chunks = mean_run <= 48 ? 1 : (mean_run <= 120 ? 2 : 4);
         if (const char* env = std::getenv("SPMV_TILED_CHUNKS")) {
             const int v = std::atoi(env);
             if (v == 1 || v == 2 || v == 4) plan->run_chunks = v;

@@ -306,7 +306,11 @@ class ShardedPageRank:
                     if p == self.rank:
                         continue
                     if peer_devices is not None and which == 0 and peer_devices[p] != peer_devices[self.rank]:
-                        lib().spmv_c_enable_peer_access(int(peer_devices[p]))   # best effort; the open below decides
+                        # stores into a peer's memory need peer access from THIS device; without it the
+                        # mapping below could still open and the first store would fault, so be strict
+                        if lib().spmv_c_enable_peer_access(int(peer_devices[p])) != 0:
+                            raise RuntimeError("no peer access from device %d to device %d"
+                                               % (peer_devices[self.rank], peer_devices[p]))
                     opened = c_void_p(None)
                     if lib().spmv_c_ipc_open_handle(everyone[p][which], byref(opened)) != 0 or not opened.value:
                         raise RuntimeError("hipIpcOpenMemHandle refused for rank %d" % p)

@@ -111,6 +111,69 @@ void bucket_kernel(int num_rows, int num_tiles, int strip_cols, int tile_rows, i
     }
 }
 
+// The same two passes with the cell counters aggregated in LDS: a workgroup takes a block of
+// rows inside ONE tile, so its entries differ only in the strip; it counts them per strip in LDS
+// and touches each global cell counter once (pass 0: add the count; pass 1: reserve a range and
+// hand out its slots from an LDS cursor).  Global atomics are device-scope round trips (~21 G/s
+// chip-wide, 160 M of them = 7.7 ms on C5); this way there are num_strips per workgroup instead
+// of one per entry.  Dynamic LDS: num_strips ints in pass 0, twice that in pass 1.
+template <int LANES, int PASS>
+__global__ __launch_bounds__(kBlock)
+void bucket_lds_kernel(int num_rows, int num_tiles, int num_strips, int strip_cols, int tile_rows, int long_row,
+                       int rows_per_block, int blocks_per_tile,
+                       const int* __restrict__ row_ptrs, const int* __restrict__ cols,
+                       const float* __restrict__ vals,
+                       int* __restrict__ cell_counter, const int* __restrict__ offs,
+                       float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
+                       unsigned short* __restrict__ a_lrow,
+                       int* __restrict__ long_rows, int* __restrict__ num_long) {
+    extern __shared__ int bucket_lds[];
+    int* hist = bucket_lds;
+    int* cursor = bucket_lds + num_strips;                 // pass 1 only
+    const int tile = blockIdx.x / blocks_per_tile;
+    const long long tile_first = static_cast<long long>(tile) * tile_rows;
+    const long long row0 = tile_first + static_cast<long long>(blockIdx.x % blocks_per_tile) * rows_per_block;
+    const long long row1 = min(min(row0 + rows_per_block, tile_first + tile_rows), static_cast<long long>(num_rows));
+    for (int i = threadIdx.x; i < num_strips; i += kBlock) hist[i] = 0;
+    __syncthreads();
+
+    constexpr int kRowsPerSweep = kBlock / LANES;
+    const int lane = threadIdx.x % LANES;
+    for (long long row = row0 + threadIdx.x / LANES; row < row1; row += kRowsPerSweep) {
+        const int begin = row_ptrs[row], end = row_ptrs[row + 1];
+        if (end - begin > long_row) {
+            if (PASS == 0 && lane == 0) long_rows[atomicAdd(num_long, 1)] = static_cast<int>(row);
+            continue;
+        }
+        for (int j = begin + lane; j < end; j += LANES) atomicAdd(&hist[cols[j] / strip_cols], 1);
+    }
+    __syncthreads();
+    if (PASS == 0) {
+        for (int i = threadIdx.x; i < num_strips; i += kBlock) {
+            if (hist[i]) atomicAdd(&cell_counter[static_cast<long long>(i) * num_tiles + tile], hist[i]);
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < num_strips; i += kBlock) {
+        const long long cell = static_cast<long long>(i) * num_tiles + tile;
+        cursor[i] = hist[i] ? offs[cell] + atomicAdd(&cell_counter[cell], hist[i]) : 0;
+    }
+    __syncthreads();
+    for (long long row = row0 + threadIdx.x / LANES; row < row1; row += kRowsPerSweep) {
+        const int begin = row_ptrs[row], end = row_ptrs[row + 1];
+        if (end - begin > long_row) continue;
+        const unsigned short lrow = static_cast<unsigned short>(row - tile_first);
+        for (int j = begin + lane; j < end; j += LANES) {
+            const int c = cols[j];
+            const int strip = c / strip_cols;
+            const int at = atomicAdd(&cursor[strip], 1);
+            if (a_val) a_val[at] = vals[j];
+            a_lcol[at] = static_cast<unsigned short>(c - strip * strip_cols);
+            a_lrow[at] = lrow;
+        }
+    }
+}
+
 // ELL source: one thread per row walks the K column-major slabs (padding: col < 0).
 template <int PASS>
 __global__ __launch_bounds__(kBlock)
@@ -515,9 +578,29 @@ hipError_t dev_alloc(T** p, long long count) {
     return hipMalloc(reinterpret_cast<void**>(p), static_cast<size_t>(std::max<long long>(count, 1)) * sizeof(T));
 }
 
+constexpr int kBucketLdsMaxStrips = 7680;     // 2 x 4 B x strips of dynamic LDS stays under the 64 KiB default limit
+
 template <int LANES, int PASS>
 hipError_t launch_bucket(const CSRMatrix* A, const TiledPlan& plan, int* counter, const int* offs,
                          int* num_long, hipStream_t s) {
+    if (plan.num_strips <= kBucketLdsMaxStrips) {
+        // ~16 K entries per workgroup, whole sweeps of rows, never across a tile boundary
+        constexpr int kRowsPerSweep = kBlock / LANES;
+        const double mean = std::max(1.0, static_cast<double>(A->nnz) / std::max(A->num_rows, 1));
+        long long rows_per_block = static_cast<long long>(16384.0 / mean);
+        rows_per_block = std::max<long long>(kRowsPerSweep, rows_per_block / kRowsPerSweep * kRowsPerSweep);
+        rows_per_block = std::min<long long>(rows_per_block, (plan.tile_rows + kRowsPerSweep - 1) / kRowsPerSweep * kRowsPerSweep);
+        const int blocks_per_tile = static_cast<int>((plan.tile_rows + rows_per_block - 1) / rows_per_block);
+        const long long grid = static_cast<long long>(plan.num_tiles) * blocks_per_tile;
+        if (grid <= 0x7fffffffLL) {
+            const size_t lds = static_cast<size_t>(plan.num_strips) * sizeof(int) * (PASS == 0 ? 1 : 2);
+            bucket_lds_kernel<LANES, PASS><<<static_cast<int>(grid), kBlock, lds, s>>>(
+                A->num_rows, plan.num_tiles, plan.num_strips, plan.strip_cols, plan.tile_rows, plan.long_row,
+                static_cast<int>(rows_per_block), blocks_per_tile, A->d_row_ptrs, A->d_col_indices, A->d_values,
+                counter, offs, plan.a_val, plan.a_lcol, plan.a_lrow, plan.long_rows, num_long);
+            return hipGetLastError();
+        }
+    }
     const int rows_per_block = kBlock / LANES;
     const int grid = (A->num_rows + rows_per_block - 1) / rows_per_block;
     bucket_kernel<LANES, PASS><<<grid, kBlock, 0, s>>>(

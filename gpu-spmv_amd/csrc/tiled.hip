@@ -316,7 +316,12 @@ void tiled_expand_kernel(const int* __restrict__ items, int num_items, int long_
                          const unsigned short* __restrict__ a_lcol,
                          const float* __restrict__ col_weight,
                          const float* __restrict__ x, int num_cols,
-                         float* __restrict__ prod, LongRows long_rows) {
+                         float* __restrict__ prod, LongRows long_rows,
+                         const PrState* __restrict__ state) {
+    // PageRank steps enqueued past convergence must leave the seed vector alone: phase 2 returns
+    // before consuming it, and the long-row wavefronts ADD into it (a later call on the same
+    // matrix would start from stale sums)
+    if (state && state->done) return;
     if (static_cast<int>(blockIdx.x) < long_blocks) {     // the long-row workgroups go first (latency-bound)
         constexpr int kPerBlock = kExpandBlock / 64;
         long_row_chunk(long_rows, blockIdx.x * kPerBlock + (threadIdx.x >> 6), x);
@@ -672,27 +677,27 @@ void choose_shape(long long num_rows, long long num_cols, long long nnz, int* st
 }
 
 template <int W, int BLOCK>
-hipError_t launch_expand_as(const TiledPlan& plan, const float* d_x, hipStream_t s) {
+hipError_t launch_expand_as(const TiledPlan& plan, const float* d_x, const PrState* d_state, hipStream_t s) {
     const LongRows lr{plan.long_chunks, plan.num_long_chunks, plan.csr_nnz, plan.csr_cols, plan.csr_vals, plan.seed};
     const int long_blocks = xcd_grid((plan.num_long_chunks + BLOCK / 64 - 1) / (BLOCK / 64));
     const int grid = long_blocks + xcd_grid(plan.num_items);
     if (plan.col_weight) {
         tiled_expand_kernel<W, BLOCK, true><<<grid, BLOCK, 0, s>>>(
-            plan.items, plan.num_items, long_blocks, nullptr, plan.a_lcol, plan.col_weight, d_x, plan.num_cols, plan.prod, lr);
+            plan.items, plan.num_items, long_blocks, nullptr, plan.a_lcol, plan.col_weight, d_x, plan.num_cols, plan.prod, lr, d_state);
     } else {
         tiled_expand_kernel<W, BLOCK, false><<<grid, BLOCK, 0, s>>>(
-            plan.items, plan.num_items, long_blocks, plan.a_val, plan.a_lcol, nullptr, d_x, plan.num_cols, plan.prod, lr);
+            plan.items, plan.num_items, long_blocks, plan.a_val, plan.a_lcol, nullptr, d_x, plan.num_cols, plan.prod, lr, d_state);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_expand(const TiledPlan& plan, const float* d_x, hipStream_t s) {
+hipError_t launch_expand(const TiledPlan& plan, const float* d_x, const PrState* d_state, hipStream_t s) {
     if (plan.num_items == 0 && plan.num_long_chunks == 0) return hipSuccess;
     switch (plan.strip_cols) {
-        case 4096:  return launch_expand_as<4096, 512>(plan, d_x, s);
-        case 8192:  return launch_expand_as<8192, 512>(plan, d_x, s);
-        case 16384: return launch_expand_as<16384, 512>(plan, d_x, s);
-        default:    return launch_expand_as<32768, 1024>(plan, d_x, s);   // 128 KiB of LDS: one workgroup per CU
+        case 4096:  return launch_expand_as<4096, 512>(plan, d_x, d_state, s);
+        case 8192:  return launch_expand_as<8192, 512>(plan, d_x, d_state, s);
+        case 16384: return launch_expand_as<16384, 512>(plan, d_x, d_state, s);
+        default:    return launch_expand_as<32768, 1024>(plan, d_x, d_state, s);   // 128 KiB of LDS: one workgroup per CU
     }
 }
 
@@ -1021,7 +1026,7 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
 } // namespace
 
 hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipStream_t s) {
-    const hipError_t e = launch_expand(plan, d_x, s);       // phase 1 + the long rows
+    const hipError_t e = launch_expand(plan, d_x, nullptr, s);       // phase 1 + the long rows
     if (e != hipSuccess) return e;
     return launch_reduce(plan, d_y, s);
 }
@@ -1031,9 +1036,9 @@ hipError_t tiled_pagerank_step(const TiledPlan& plan, int row_offset, int n_glob
                                const unsigned char* d_dangling, float damping,
                                const PrState* d_state, double* d_block_partials,
                                const PushTargets& push, hipStream_t s) {
-    // After convergence the reduce kernel returns before touching r_new; the other kernels
-    // then only rewrite scratch (product stream, seed vector), which nothing reads.
-    const hipError_t e = launch_expand(plan, d_r_old, s);   // phase 1 + the long rows
+    // After convergence both kernels return at once: r_new, the product stream and the seed vector
+    // stay as the last committed step left them.
+    const hipError_t e = launch_expand(plan, d_r_old, d_state, s);   // phase 1 + the long rows (no-op once done)
     if (e != hipSuccess) return e;
     return launch_pagerank_reduce(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
                                   d_block_partials, push, s);

@@ -207,6 +207,34 @@ def test_pagerank_through_the_tiled_engine(gpu, oracle):
     gpu.csr_destroy(A)
 
 
+def test_repeated_calls_on_a_power_law_graph_with_long_rows(gpu, oracle):
+    """In-degrees follow a power law, so some rows are too long for the cells of the tiled engine: the
+    first few thousand are summed through LDS accumulators in phase 1, the rest by the direct path,
+    both via the seed vector.  A second pagerank() on the same matrix, and an SpMV after it, must not
+    see anything the first call's run-ahead step left behind."""
+    n = 400_000
+    lens = gpu.synth.power_law_lengths(31, n, max_len=20000, n_cols=n)
+    rp, ci, _ = gpu.synth.stratified_csr(31, 0, lens, n)
+    va = gpu.synth.column_stochastic_values(ci, n)
+    A = upload(gpu, rp, ci, va, n)
+    first = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
+    info = gpu.csr_tiled_info(A)
+    assert info is not None and info["long_rows"] > 2048                   # both long-row paths are in use
+    second = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
+    want, iters, res, conv = oracle.pagerank(rp, ci, va, num_cols=n, wide_sums=True)
+    for r in (first, second):
+        assert r.converged == conv and abs(r.iterations - iters) <= 1
+        compare(r.ranks, want)
+    x = np.abs(gpu.synth.vector(31, 2, n)) + np.float32(0.01)
+    d_x, d_y = gpu.CudaBuffer(n), gpu.CudaBuffer(n)
+    d_x.copyFromHost(x, n)
+    assert gpu.spmv_csr(A, d_x, d_y, gpu.SpMVConfig(2, 256, True), n).error_code == 0
+    got = d_y.copyToHost(n)
+    ref = oracle.spmv_csr(rp, ci, va, x)
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30)) <= 1e-5
+    gpu.csr_destroy(A)
+
+
 def test_config5_pagerank_full_size_invariants(gpu):
     """BASELINE config 5: PageRank (d = 0.85, tol = 1e-6) on the 10 M-node / 160 M-edge
     column-stochastic matrix built in HBM.  Size-independent properties (reference

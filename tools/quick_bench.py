@@ -71,6 +71,10 @@ def main():
                 dt = time.perf_counter() - t0
             print(f"pagerank() n={n} k={k}: {dt*1e3:.2f} ms for {res.iterations} iterations = {dt*1e6/max(res.iterations,1):.1f} us/iteration", flush=True)
             counts.release(); A.close()
+    if "c5pl" in which:       # power-law rows at C5 scale (what a real PageRank graph looks like)
+        A = wl.power_law_csr_device(42, 10_000_000, 10_000_000)
+        print("c5pl nnz", A.nnz, flush=True); report("10M power-law", A, kernels=(12, 2))
+        print("plan", spmv.csr_tiled_info(A.handle), flush=True); A.close()
     if "c5only" in which:
         A = wl.uniform_csr_device(42, 10_000_000, 10_000_000, 16); report("c5 10M x 16", A, kernels=(11,)); A.close()
     if "c5" in which:

@@ -62,6 +62,9 @@ inline bool spmv_validate_dimensions(int num_cols, int vec_size) {
 
 // Enqueue-only variant: validates, launches on `stream`, does not time or
 // synchronise.  Returns an SpMVError as int.  Safe inside hipGraph capture.
+// A matrix's auxiliary data (merge tables, the LDS-tiled plan with its product stream) is scratch
+// shared by all calls on that matrix: calls on the SAME matrix must be ordered (one stream, or
+// events between streams); calls on different matrices may overlap freely.
 int spmv_csr_async(const CSRMatrix* A, const float* d_x, float* d_y,
                    const SpMVConfig* config, int vec_size, hipStream_t stream);
 int spmv_ell_async(const ELLMatrix* A, const float* d_x, float* d_y,

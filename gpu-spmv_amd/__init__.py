@@ -155,6 +155,7 @@ _SIGNATURES = {
     "spmv_c_csr_to_gpu": (c_int, [POINTER(CSRMatrix)]),
     "spmv_c_csr_from_gpu": (c_int, [POINTER(CSRMatrix)]),
     "spmv_c_csr_free_gpu": (None, [POINTER(CSRMatrix)]),
+    "spmv_c_csr_invalidate_gpu_cache": (None, [POINTER(CSRMatrix)]),
     "spmv_c_csr_serialize": (c_int, [POINTER(CSRMatrix), c_char_p]),
     "spmv_c_csr_deserialize": (c_int, [POINTER(CSRMatrix), c_char_p]),
     "spmv_c_csr_compute_stats": (c_int, [POINTER(CSRMatrix), POINTER(CSRStats)]),
@@ -169,6 +170,7 @@ _SIGNATURES = {
     "spmv_c_ell_to_gpu": (c_int, [POINTER(ELLMatrix)]),
     "spmv_c_ell_from_gpu": (c_int, [POINTER(ELLMatrix)]),
     "spmv_c_ell_free_gpu": (None, [POINTER(ELLMatrix)]),
+    "spmv_c_ell_invalidate_gpu_cache": (None, [POINTER(ELLMatrix)]),
     "spmv_c_ell_serialize": (c_int, [POINTER(ELLMatrix), c_char_p]),
     "spmv_c_ell_deserialize": (c_int, [POINTER(ELLMatrix), c_char_p]),
     "spmv_c_ell_index": (c_int, [c_int, c_int, c_int]),
@@ -423,6 +425,11 @@ def csr_free_gpu(mat) -> None:
     lib().spmv_c_csr_free_gpu(mat)
 
 
+def csr_invalidate_gpu_cache(mat) -> None:
+    """After writing into the matrix's device arrays in place: drop the cached plan / tables."""
+    lib().spmv_c_csr_invalidate_gpu_cache(mat)
+
+
 def csr_serialize(mat, filename) -> int:
     return lib().spmv_c_csr_serialize(mat, os.fsencode(filename) if filename is not None else None)
 
@@ -521,6 +528,10 @@ def ell_from_gpu(mat) -> int:
 
 def ell_free_gpu(mat) -> None:
     lib().spmv_c_ell_free_gpu(mat)
+
+
+def ell_invalidate_gpu_cache(mat) -> None:
+    lib().spmv_c_ell_invalidate_gpu_cache(mat)
 
 
 def ell_serialize(mat, filename) -> int:

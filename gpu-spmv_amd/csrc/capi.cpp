@@ -178,6 +178,7 @@ float spmv_c_csr_get_element(const spmv_c_csr* mat, int row, int col) {
 int spmv_c_csr_to_gpu(spmv_c_csr* mat) { return csr_to_gpu(cxx(mat)); }
 int spmv_c_csr_from_gpu(spmv_c_csr* mat) { return csr_from_gpu(cxx(mat)); }
 void spmv_c_csr_free_gpu(spmv_c_csr* mat) { csr_free_gpu(cxx(mat)); }
+void spmv_c_csr_invalidate_gpu_cache(const spmv_c_csr* mat) { csr_invalidate_gpu_cache(cxx(mat)); }
 int spmv_c_csr_serialize(const spmv_c_csr* mat, const char* filename) {
     return csr_serialize(cxx(mat), filename);
 }
@@ -224,6 +225,7 @@ float spmv_c_ell_get_element(const spmv_c_ell* mat, int row, int col) {
 int spmv_c_ell_to_gpu(spmv_c_ell* mat) { return ell_to_gpu(cxx(mat)); }
 int spmv_c_ell_from_gpu(spmv_c_ell* mat) { return ell_from_gpu(cxx(mat)); }
 void spmv_c_ell_free_gpu(spmv_c_ell* mat) { ell_free_gpu(cxx(mat)); }
+void spmv_c_ell_invalidate_gpu_cache(const spmv_c_ell* mat) { ell_invalidate_gpu_cache(cxx(mat)); }
 int spmv_c_ell_serialize(const spmv_c_ell* mat, const char* filename) {
     return ell_serialize(cxx(mat), filename);
 }

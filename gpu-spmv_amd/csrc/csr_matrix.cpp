@@ -194,6 +194,10 @@ void csr_free_gpu(CSRMatrix* mat) {
     mat->owns_device_memory = false;
 }
 
+void csr_invalidate_gpu_cache(const CSRMatrix* mat) {
+    if (mat && mat->d_row_ptrs) detail::aux_drop(mat->d_row_ptrs);
+}
+
 int csr_serialize(const CSRMatrix* mat, const char* filename) {
     if (!mat || !filename) return detail::code(SpMVError::INVALID_ARGUMENT);
 

@@ -232,6 +232,10 @@ void ell_free_gpu(ELLMatrix* mat) {
     mat->owns_device_memory = false;
 }
 
+void ell_invalidate_gpu_cache(const ELLMatrix* mat) {
+    if (mat && mat->d_col_indices) detail::ell_aux_drop(mat->d_col_indices);
+}
+
 int ell_serialize(const ELLMatrix* mat, const char* filename) {
     if (!mat || !filename) return detail::code(SpMVError::INVALID_ARGUMENT);
 

@@ -42,6 +42,11 @@ float csr_get_element(const CSRMatrix* mat, int row, int col);   // 0.0f when ab
 int csr_to_gpu(CSRMatrix* mat);     // (re)uploads host arrays to HBM
 int csr_from_gpu(CSRMatrix* mat);   // downloads device arrays into the host arrays
 void csr_free_gpu(CSRMatrix* mat);
+// extension: per-matrix auxiliary data (row statistics, merge-path tables, the LDS-tiled plan with its
+// copy of the entries) is derived from the device arrays at first use and cached until they are
+// freed or re-uploaded.  After writing into d_values / d_col_indices / d_row_ptrs IN PLACE, call this
+// so that the next call rebuilds it.
+void csr_invalidate_gpu_cache(const CSRMatrix* mat);
 
 // File layout: int32 rows, cols, nnz; float[nnz]; int32[nnz]; int32[rows+1] (native endian).
 int csr_serialize(const CSRMatrix* mat, const char* filename);

@@ -43,6 +43,8 @@ float ell_get_element(const ELLMatrix* mat, int row, int col);
 int ell_to_gpu(ELLMatrix* mat);
 int ell_from_gpu(ELLMatrix* mat);
 void ell_free_gpu(ELLMatrix* mat);
+// extension: drops the cached auxiliary data of the device arrays (see csr_invalidate_gpu_cache)
+void ell_invalidate_gpu_cache(const ELLMatrix* mat);
 
 // File layout: int32 rows, cols, K; float[rows*K]; int32[rows*K] (column-major).
 int ell_serialize(const ELLMatrix* mat, const char* filename);

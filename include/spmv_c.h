@@ -150,6 +150,8 @@ float spmv_c_csr_get_element(const spmv_c_csr* mat, int row, int col);
 int spmv_c_csr_to_gpu(spmv_c_csr* mat);
 int spmv_c_csr_from_gpu(spmv_c_csr* mat);
 void spmv_c_csr_free_gpu(spmv_c_csr* mat);
+/* extension: forget the cached auxiliary data after the device arrays were modified in place */
+void spmv_c_csr_invalidate_gpu_cache(const spmv_c_csr* mat);
 int spmv_c_csr_serialize(const spmv_c_csr* mat, const char* filename);
 int spmv_c_csr_deserialize(spmv_c_csr* mat, const char* filename);
 int spmv_c_csr_compute_stats(const spmv_c_csr* mat, spmv_c_csr_stats* out);
@@ -169,6 +171,7 @@ float spmv_c_ell_get_element(const spmv_c_ell* mat, int row, int col);
 int spmv_c_ell_to_gpu(spmv_c_ell* mat);
 int spmv_c_ell_from_gpu(spmv_c_ell* mat);
 void spmv_c_ell_free_gpu(spmv_c_ell* mat);
+void spmv_c_ell_invalidate_gpu_cache(const spmv_c_ell* mat);
 int spmv_c_ell_serialize(const spmv_c_ell* mat, const char* filename);
 int spmv_c_ell_deserialize(spmv_c_ell* mat, const char* filename);
 int spmv_c_ell_index(int row, int k, int num_rows);

@@ -336,6 +336,28 @@ def test_tiled_engine_folds_column_uniform_values(gpu, oracle, monkeypatch):
     assert max_rel_err(oracle.spmv_csr(rp, ci, ones, x), got_1) <= REORDER_TOL
 
 
+def test_values_rewritten_in_place_need_a_cache_invalidation(gpu, oracle):
+    """The tiled plan keeps its own copy of the entries: after the device values are overwritten in place
+    the caller drops the cached data (csr_invalidate_gpu_cache) and the next call sees the new values."""
+    rows, cols, k = 200_000, 300_000, 8
+    rp, ci, va = gpu.synth.uniform_csr(5, 0, rows, cols, k)
+    x = gpu.synth.vector(5, 1, cols)
+    A = gpu.csr_from_arrays(rows, cols, rp, ci, va)
+    assert gpu.csr_to_gpu(A) == 0
+    d_x, d_y = gpu.CudaBuffer(cols), gpu.CudaBuffer(rows)
+    d_x.copyFromHost(x, cols)
+    cfg = gpu.SpMVConfig(kernel_type=1, use_texture=True)
+    assert gpu.spmv_csr(A, d_x, d_y, cfg, cols).error_code == 0 and gpu.csr_has_tiled_plan(A)
+    assert reorder_err(rp, ci, va, x, oracle.spmv_csr(rp, ci, va, x), d_y.copyToHost(rows)) <= REORDER_TOL
+    doubled = (va * np.float32(2.0)).astype(np.float32)
+    assert gpu.lib().spmv_c_memcpy_h2d(A.contents.d_values, doubled.ctypes.data, doubled.nbytes) == 0
+    gpu.csr_invalidate_gpu_cache(A)
+    assert not gpu.csr_has_tiled_plan(A)
+    assert gpu.spmv_csr(A, d_x, d_y, cfg, cols).error_code == 0
+    assert reorder_err(rp, ci, doubled, x, oracle.spmv_csr(rp, ci, doubled, x), d_y.copyToHost(rows)) <= REORDER_TOL
+    gpu.csr_destroy(A)
+
+
 def test_use_texture_on_small_matrix_keeps_direct_kernels(gpu, oracle):
     """Below the size where x leaves L2 the hint is ignored (no plan is built)."""
     rp, ci, va = gpu.synth.uniform_csr(1, 0, 5000, 20000, 8)

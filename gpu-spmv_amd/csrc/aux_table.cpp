@@ -69,8 +69,9 @@ const TiledPlan* tiled_plan_for(const CSRMatrix* A, hipStream_t s) {
     std::lock_guard<std::mutex> building(g_build_lock);
     CsrAux* aux = aux_lookup(A->d_row_ptrs, true);
     if (aux->tiled && (aux->tiled->num_rows != A->num_rows || aux->tiled->num_cols != A->num_cols ||
-                       aux->tiled->csr_nnz != A->nnz)) {
-        tiled_free(aux->tiled);       // header changed under the same device arrays
+                       aux->tiled->csr_nnz != A->nnz || aux->tiled->csr_cols != A->d_col_indices ||
+                       aux->tiled->csr_vals != A->d_values)) {
+        tiled_free(aux->tiled);       // header or arrays changed under the same row-pointer array
         aux->tiled = nullptr;
         aux->tiled_failed = false;
     }

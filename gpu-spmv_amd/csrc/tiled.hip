@@ -27,7 +27,7 @@
 //   folding : when every stored entry of a column has the same bits, the value stream is dropped
 //        and phase 1 gathers w_j * x_j from LDS (column_weight_probe_kernel, FOLD instantiation).
 //   both phases walk their work lists in per-XCD contiguous slices (xcd_contiguous).
-//   long rows (more than min(1024, 2 x strips) entries) would make many lanes fight over one
+//   long rows (more than min(2048, 2 or 4 entries per strip)) would make many lanes fight over one
 //        LDS word; they are left out of the cells and summed in 512-entry chunks by extra
 //        wavefronts of the phase-1 grid (direct gather) into a side vector that seeds the tiles.
 //
@@ -60,7 +60,7 @@ using namespace dev;
 //   R = any multiple of 64 in [64, kMaxTileRows]: dynamic LDS in phase 2
 constexpr int kMaxItemEntries = 65536;   // phase-1 work item size bounds (entries)
 constexpr int kMinItemEntries = 4096;
-constexpr int kMaxLongRow = 1024;     // rows longer than min(this, 2 * strips) bypass the cells
+constexpr int kMaxLongRow = 2048;     // rows longer than min(this, 2 or 4 entries per strip) bypass the cells
 constexpr int kLongChunk = 512;       // entries per wavefront of the long-row path
 constexpr long long kMaxCells = 1LL << 26;
 constexpr long long kTargetRun = 128;        // wanted mean entries per cell (run length seen by phase 2)
@@ -499,6 +499,12 @@ __device__ __forceinline__ void tile_accumulate(float* tile, int R, int tile_ind
                             r[j * U + u] = first ? rv[0] : -1;
                             p[j * U + u + 1] = pv[1];
                             r[j * U + u + 1] = (ok && i + 1 < len[j]) ? rv[1] : -1;
+                            // two neighbouring entries of one row (the build places a row's entries of a
+                            // cell side by side): one LDS add instead of two colliding ones
+                            if (r[j * U + u] >= 0 && r[j * U + u] == r[j * U + u + 1]) {
+                                p[j * U + u] = __fadd_rn(p[j * U + u], p[j * U + u + 1]);
+                                r[j * U + u + 1] = -1;
+                            }
                         }
                     }
                 } else {
@@ -839,9 +845,15 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     const long long cells = static_cast<long long>(plan->num_strips) * plan->num_tiles;
     // A row spreads over the strips; once it averages more than ~2 entries per cell its lanes
     // start to collide on one LDS word in phase 2, so such rows take the direct path instead.
-    int long_factor = 2;
+    // Where the line sits depends on what the direct path's gathers cost: with x inside the L2s
+    // (<= 8 MB) they are cheap and 2 entries per cell is the limit (C4, 62 strips: 124 entries 53 us,
+    // 248 entries 55 us); with a large x every gather is a fabric request and rows stay in the cells
+    // longer (10 M x 10 M power-law matrix, 611 strips: limit 1024 475 us, 2048 449 us, 4096 454 us).
+    int long_factor = static_cast<long long>(src.cols) * 4 > (8LL << 20) ? 4 : 2;
     if (const char* env = std::getenv("SPMV_TILED_LONG_FACTOR")) long_factor = std::max(1, std::atoi(env));
-    plan->long_row = A ? std::max(64, std::min(kMaxLongRow, long_factor * plan->num_strips)) : 0x7fffffff;
+    int long_cap = kMaxLongRow;
+    if (const char* env = std::getenv("SPMV_TILED_LONG_CAP")) long_cap = std::max(64, std::atoi(env));
+    plan->long_row = A ? std::max(64, std::min(long_cap, long_factor * plan->num_strips)) : 0x7fffffff;
     const long long long_capacity = src.nnz / plan->long_row + 1;
 
     int *cnt = nullptr, *offs = nullptr, *strip_begin = nullptr, *num_long = nullptr;

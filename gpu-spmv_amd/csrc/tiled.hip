@@ -962,15 +962,22 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         e = dev_alloc(&plan->col_weight, plan->num_cols);
         if (e == hipSuccess) e = hipMemsetAsync(plan->col_weight, 0, static_cast<size_t>(plan->num_cols) * sizeof(float), s);
         if (e == hipSuccess) e = hipMemsetAsync(differs, 0, sizeof(int), s);
-        if (e == hipSuccess) {
-            column_weight_probe_kernel<0><<<grid, kBlock, 0, s>>>(src_cols, src_vals, src.nnz, plan->col_weight, differs);
-            column_weight_probe_kernel<1><<<grid, kBlock, 0, s>>>(src_cols, src_vals, src.nnz, plan->col_weight, differs);
-            e = hipGetLastError();
-        }
+        // first the leading 1 M entries only: with arbitrary values a column that occurs twice there
+        // already differs, and the two full passes (6 ms on C5) are skipped
         int host_differs = 1;
-        if (e == hipSuccess) e = hipMemcpyAsync(&host_differs, differs, sizeof(int), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return cleanup(e);
+        const long long sample = std::min<long long>(src.nnz, 1LL << 20);
+        for (long long count : {sample, static_cast<long long>(src.nnz)}) {
+            const int launch = static_cast<int>(std::min<long long>((count + kBlock - 1) / kBlock, grid));
+            if (e == hipSuccess) {
+                column_weight_probe_kernel<0><<<launch, kBlock, 0, s>>>(src_cols, src_vals, count, plan->col_weight, differs);
+                column_weight_probe_kernel<1><<<launch, kBlock, 0, s>>>(src_cols, src_vals, count, plan->col_weight, differs);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(&host_differs, differs, sizeof(int), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return cleanup(e);
+            if (host_differs || count == src.nnz) break;
+        }
         if (host_differs) {
             (void)hipFree(plan->col_weight);
             plan->col_weight = nullptr;

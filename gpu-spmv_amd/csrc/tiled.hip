@@ -764,7 +764,11 @@ bool eligible_dims(long long rows, long long cols, long long nnz) {
         // (69 vs 71 us), 131072 columns 60 vs 74 us, 262144 columns 57 vs 76 us
         return env ? std::atoll(env) : 65536LL;
     }();
-    if (!enabled || rows <= 0 || nnz < (1 << 20) || cols < min_cols) return false;
+    static const long long min_nnz = [] {
+        const char* env = std::getenv("SPMV_TILED_MIN_NNZ");      // tests force small matrices through the engine
+        return env ? std::atoll(env) : 1LL << 20;
+    }();
+    if (!enabled || rows <= 0 || nnz < min_nnz || cols < min_cols) return false;
     int w = 0, r = 0;
     choose_shape(rows, cols, nnz, &w, &r);
     return ((cols + w - 1) / w) * ((rows + r - 1) / r) <= kMaxCells;

@@ -1,0 +1,21 @@
+"""The LDS-tiled engine normally takes only large matrices (>= 65536 columns, >= 1 M entries).  This test
+lowers the thresholds (environment, read once per process => a worker process) and pushes ~150 SMALL matrices
+of awkward shapes through it — single row / column, sizes straddling the strip and tile sizes, ragged and
+empty rows, rows far beyond the long-row limit, value-folded columns, ELL sources — against the CPU oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_small_and_awkward_shapes_through_the_tiled_engine(gpu):
+    env = dict(os.environ, SPMV_TILED_MIN_COLS="1", SPMV_TILED_MIN_NNZ="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tiled_small_shapes_worker.py")],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "tiled small shapes:" in out.stdout

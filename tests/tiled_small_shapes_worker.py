@@ -1,0 +1,96 @@
+"""Worker of tests/test_gpu_tiled_small_shapes.py: run with SPMV_TILED_MIN_COLS / SPMV_TILED_MIN_NNZ set so
+that SMALL matrices go through the LDS-tiled engine, and compare every case with the CPU oracle.
+(The thresholds are read once per process, hence the separate process.)"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+spmv = importlib.import_module("gpu-spmv_amd")
+oracle = importlib.import_module("oracle")
+from conftest import reorder_err  # noqa: E402
+
+
+def run_case(rng, rows, cols, lens, fold, ell):
+    lens = np.minimum(lens, cols).astype(np.int64)
+    # distinct ascending columns per row (a draw with repeats, de-duplicated: rows may come out a little shorter)
+    per_row = [np.unique(rng.integers(0, cols, size=n)) if n < cols else np.arange(cols) for n in lens]
+    lens = np.array([r.size for r in per_row], dtype=np.int64)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = (np.concatenate(per_row) if per_row else np.empty(0)).astype(np.int32)
+    if fold:      # every column one value: the plan folds the values away
+        weight = rng.uniform(0.1, 2.0, size=cols).astype(np.float32)
+        va = weight[ci]
+    else:
+        va = rng.uniform(-1, 1, size=ci.size).astype(np.float32)
+    x = rng.uniform(-1, 1, size=cols).astype(np.float32)
+    want = oracle.spmv_csr(rp, ci, va, x)
+    d_x, d_y = spmv.CudaBuffer(cols), spmv.CudaBuffer(rows)
+    d_x.copyFromHost(x, cols)
+    if ell:
+        import ctypes
+        kk, ecols, evals = oracle.ell_from_csr(rp, ci, va)
+        E = spmv.ell_create(rows, cols, kk)
+        ctypes.memmove(E.contents.col_indices, ecols.ctypes.data, ecols.nbytes)
+        ctypes.memmove(E.contents.values, evals.ctypes.data, evals.nbytes)
+        assert spmv.ell_to_gpu(E) == 0
+        cfg = spmv.SpMVConfig(kernel_type=spmv.SpMVConfig.ELL_KERNEL, use_texture=True)
+        for _ in range(2):
+            assert spmv.spmv_ell(E, d_x, d_y, cfg, cols).error_code == 0
+        got = d_y.copyToHost(rows)
+        spmv.ell_destroy(E)
+        return reorder_err(rp, ci, va, x, want, got), True
+    A = spmv.csr_from_arrays(rows, cols, rp, ci, va)
+    assert spmv.csr_to_gpu(A) == 0
+    worst, planned = 0.0, False
+    for kernel in (1, 2):
+        for _ in range(2):          # the second call reuses the plan (and meets whatever the first left behind)
+            res = spmv.spmv_csr(A, d_x, d_y, spmv.SpMVConfig(kernel_type=kernel, use_texture=True), cols)
+            assert res.error_code == 0
+            worst = max(worst, reorder_err(rp, ci, va, x, want, d_y.copyToHost(rows)))
+        planned = planned or bool(spmv.csr_has_tiled_plan(A))
+    info = spmv.csr_tiled_info(A)
+    if fold and info is not None and info["entries_in_cells"] > 0:
+        assert info["values_folded"], (rows, cols, info)
+    spmv.csr_destroy(A)
+    return worst, planned
+
+
+def main():
+    spmv.require_gpu()
+    rng = np.random.default_rng(2024)
+    shapes = [(1, 1), (1, 5000), (3, 4097), (64, 4096), (65, 8193), (1000, 70_000), (4999, 33_000),
+              (20_000, 100), (9793, 9793), (130, 200_000)]
+    cases = planned_cases = 0
+    worst = 0.0
+    for rows, cols in shapes:
+        for kind in ("uniform", "ragged", "long", "empty"):
+            if kind == "uniform":
+                lens = np.full(rows, min(cols, 7))
+            elif kind == "ragged":
+                lens = rng.integers(0, min(cols, 40) + 1, size=rows)
+            elif kind == "long":       # a few rows far beyond the long-row limit, many empty ones
+                lens = rng.integers(0, 3, size=rows)
+                lens[rng.integers(0, rows, size=min(rows, 3))] = min(cols, 5000)
+            else:
+                lens = np.zeros(rows, dtype=np.int64)
+                lens[rows // 2] = min(cols, 3)
+            for fold in (False, True):
+                for ell in (False, True):
+                    if ell and (kind == "long" or rows * int(max(lens.max(), 1)) > 4_000_000):
+                        continue
+                    err, planned = run_case(rng, rows, cols, lens, fold, ell)
+                    assert err <= 1e-5, (rows, cols, kind, fold, ell, err)
+                    worst = max(worst, err)
+                    cases += 1
+                    planned_cases += int(planned)
+    assert planned_cases >= cases // 2, (planned_cases, cases)     # the thresholds really were lowered
+    print("tiled small shapes: %d cases, %d through the tiled engine, worst error %.3g" % (cases, planned_cases, worst))
+
+
+if __name__ == "__main__":
+    main()

@@ -89,6 +89,28 @@ def main():
                     cases += 1
                     planned_cases += int(planned)
     assert planned_cases >= cases // 2, (planned_cases, cases)     # the thresholds really were lowered
+
+    # PageRank on small graphs through the same engine (fused update in phase 2, seeds of the hub rows,
+    # dangling mask read off the folded column weights), twice per graph, against the oracle
+    for n, k in ((50, 3), (1000, 8), (5000, 12), (9793, 5)):
+        per_row = [np.unique(rng.integers(0, n, size=k)) for _ in range(n)]
+        per_row[n // 3] = np.arange(0, n, 2)                       # a hub: far beyond the long-row limit
+        dangling = np.array([1, n // 2, n - 1])
+        per_row = [r[~np.isin(r, dangling)] for r in per_row]
+        lens = np.array([r.size for r in per_row], dtype=np.int64)
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        ci = np.concatenate(per_row).astype(np.int32)
+        va = spmv.synth.column_stochastic_values(ci, n)
+        want, iters, _, conv = oracle.pagerank(rp, ci, va, num_cols=n, wide_sums=True)
+        A = spmv.csr_from_arrays(n, n, rp, ci, va)
+        assert spmv.csr_to_gpu(A) == 0
+        for _ in range(2):
+            r = spmv.pagerank(A, spmv.PageRankConfig(0.85, 1e-6, 100))
+            assert spmv.csr_has_tiled_plan(A)
+            assert r.converged == conv and abs(r.iterations - iters) <= 1, (n, r.iterations, iters)
+            assert np.max(np.abs(r.ranks - want)) < 1e-6, (n, float(np.max(np.abs(r.ranks - want))))
+        spmv.csr_destroy(A)
+        cases += 1
     print("tiled small shapes: %d cases, %d through the tiled engine, worst error %.3g" % (cases, planned_cases, worst))
 
 

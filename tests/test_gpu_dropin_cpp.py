@@ -27,3 +27,13 @@ def test_cpp_dropin_caller(gpu):
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout + out.stderr
+
+
+def test_reference_gtest_cases_restated_in_cpp(gpu):
+    """tests/cpp/reference_suite.cpp: the 48 cases of the reference's eight gtest files, same names, compiled
+    with plain g++ against the drop-in headers (source-level compatibility of the C++ boundary)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "reference_suite")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "all reference cases passed" in out.stdout, out.stdout[-4000:] + out.stderr[-2000:]
+    assert out.stdout.count("[  OK  ]") == 48, out.stdout[-2000:]

@@ -127,9 +127,16 @@ def main():
 
     # ---- N > 1: how the new slices travel.  "push" = the step kernels store them straight into the
     # peers' vectors (IPC-mapped, xGMI point-to-point) + a 16-byte all-reduce; "gather" = one RCCL
-    # all-gather per step.  Push is used only if every rank could map every peer AND a 4-step trial
-    # reproduces the gather path's vector on every rank; otherwise the run falls back to gather.
+    # all-gather per step.  Push is a candidate only if every rank could map every peer AND a 4-step
+    # trial reproduces the gather path's vector on every rank; then both are timed and the faster runs.
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     exchange = "none"
+    exchange_ms = None
     if world > 1:
         exchange = "gather"
         want = os.environ.get("SPMV_PR_EXCHANGE", "auto")
@@ -149,17 +156,31 @@ def main():
             worst = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max())
             flag = torch.tensor([1 if worst <= 1e-4 else 0], dtype=torch.int32, device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            pr.mode = "push" if int(flag.item()) == 1 else "gather"
-            exchange = pr.mode if pr.mode == "push" else "gather (push trial disagreed: rel %.3g)" % worst
+            if int(flag.item()) == 1:
+                # both exchanges are correct here: time each for a few steps (barrier-bracketed, max over
+                # ranks) and run the bench on the faster one; the pair of timings goes into the JSON line
+                def timed(mode, steps=20):
+                    pr.mode = mode
+                    pr.reset()
+                    for i in range(3):
+                        pr.iterate(i, damping, never)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for i in range(3, 3 + steps):
+                        pr.iterate(i, damping, never)
+                    barrier()
+                    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    return float(t.item()) / steps * 1e3
+                exchange_ms = {"gather": round(timed("gather"), 4), "push": round(timed("push"), 4)}
+                pr.mode = want if want == "push" else min(exchange_ms, key=exchange_ms.get)
+                exchange = pr.mode
+            else:
+                pr.mode = "gather"
+                exchange = "gather (push trial disagreed: rel %.3g)" % worst
         elif want in ("auto", "push"):
             exchange = "gather (peer mapping unavailable: %s)" % getattr(pr, "_push_error", "a peer failed")
         pr.reset()
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     step = 0
     for _ in range(args.warmup):
@@ -224,7 +245,7 @@ def main():
                        " + slices pushed into the peers' vectors by the step kernels (xGMI stores) + RCCL all-reduce of 16 B per step"
                        if exchange == "push" else
                        " + one RCCL all-gather per step (%d f32/rank, partial sums in the slice tails)" % layout.stride)),
-                   "exchange": exchange,
+                   "exchange": exchange, "exchange_ms_per_step": exchange_ms,
                    "values_folded": bool(plan_info and plan_info.get("values_folded"))},
         "gflops": round(2.0 * nnz_total * args.steps / elapsed / 1e9, 1),
         "pagerank_iters_per_sec": round(args.steps / elapsed, 2),

@@ -31,6 +31,17 @@ __global__ __launch_bounds__(256) void phase1(const float* __restrict__ vals, co
     }
 }
 
+// float add on an LDS word by compare-and-swap on its integer image (what csrc/tiled.hip uses)
+__device__ __forceinline__ void cas_add(float* slot, float v) {
+    unsigned int* word = reinterpret_cast<unsigned int*>(slot);
+    unsigned int seen = *word;
+    for (;;) {
+        const unsigned int got = atomicCAS(word, seen, __float_as_uint(__uint_as_float(seen) + v));
+        if (got == seen) break;
+        seen = got;
+    }
+}
+
 template <int R>   // tile height in floats
 __global__ __launch_bounds__(256) void phase2(const float* __restrict__ prod, const unsigned short* __restrict__ lrow,
                                               float* __restrict__ y, long long per_wg) {
@@ -41,8 +52,8 @@ __global__ __launch_bounds__(256) void phase2(const float* __restrict__ prod, co
     for (long long i = begin + threadIdx.x * 4; i < begin + per_wg; i += 256 * 4) {
         const f32x4 p = *reinterpret_cast<const f32x4*>(prod + i);
         const u16x4 r = *reinterpret_cast<const u16x4*>(lrow + i);
-        atomicAdd(&ys[r[0] & (R - 1)], p[0]); atomicAdd(&ys[r[1] & (R - 1)], p[1]);
-        atomicAdd(&ys[r[2] & (R - 1)], p[2]); atomicAdd(&ys[r[3] & (R - 1)], p[3]);
+        cas_add(&ys[r[0] & (R - 1)], p[0]); cas_add(&ys[r[1] & (R - 1)], p[1]);
+        cas_add(&ys[r[2] & (R - 1)], p[2]); cas_add(&ys[r[3] & (R - 1)], p[3]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < R; i += 256) y[(long long)blockIdx.x * R + i] = ys[i];
@@ -68,7 +79,7 @@ int main() {
     const long long N = 160LL * 1000 * 1000;
     float *vals, *prod, *x, *y; unsigned short *lcol, *lrow;
     hipMalloc(&vals, N * 4); hipMalloc(&prod, N * 4); hipMalloc(&lcol, N * 2); hipMalloc(&lrow, N * 2);
-    hipMalloc(&x, 40u << 20); hipMalloc(&y, 64u << 20);
+    hipMalloc(&x, 40u << 20); hipMalloc(&y, 9760ull * 8192 * 4);   // the largest wgs x R below
     fill<<<4096, 256>>>(lcol, vals, N); fill<<<4096, 256>>>(lrow, prod, N); hipMemset(x, 0, 40u << 20);
     hipDeviceSynchronize();
     printf("N = %lld entries\n", N);

@@ -5,6 +5,8 @@ import importlib
 import numpy as np
 import pytest
 
+from conftest import reorder_err
+
 pytestmark = pytest.mark.gpu
 
 
@@ -221,3 +223,35 @@ def test_async_spmv_and_pagerank_steps_replay_from_a_hip_graph(gpu, oracle):
     torch.testing.assert_close(pr.r[0], eager, rtol=2e-6, atol=0)
     eng.close()
     gpu.csr_destroy(A)
+
+
+def test_host_threads_on_their_own_matrices(gpu, oracle):
+    """Four host threads, each with its own matrix (two of them large enough for the tiled engine, so plan
+    builds meet on the build lock), calling spmv_csr concurrently: per-thread event pairs, locked side tables."""
+    import threading
+    shapes = [(120_000, 150_000, 9), (3_000, 4_000, 11), (90_000, 200_000, 12), (500, 70_000, 30)]
+    failures = []
+
+    def worker(index, rows, cols, k):
+        try:
+            rp, ci, va = gpu.synth.uniform_csr(100 + index, 0, rows, cols, k)
+            x = gpu.synth.vector(100 + index, 1, cols)
+            want = oracle.spmv_csr(rp, ci, va, x)
+            A = gpu.csr_from_arrays(rows, cols, rp, ci, va)
+            assert gpu.csr_to_gpu(A) == 0
+            d_x, d_y = gpu.CudaBuffer(cols), gpu.CudaBuffer(rows)
+            d_x.copyFromHost(x, cols)
+            for call in range(12):
+                cfg = gpu.SpMVConfig(kernel_type=1 + call % 2, use_texture=True)
+                assert gpu.spmv_csr(A, d_x, d_y, cfg, cols).error_code == 0
+                assert reorder_err(rp, ci, va, x, want, d_y.copyToHost(rows)) <= 1e-5
+            gpu.csr_destroy(A)
+        except Exception as exc:            # noqa: BLE001 - reported by the main thread
+            failures.append((index, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(i, *shape)) for i, shape in enumerate(shapes)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not failures, failures

@@ -138,7 +138,10 @@ class HipEngine:
         self._mask = mask
         if self._shard:
             lib().spmv_c_pr_shard_destroy(self._shard)
-        # the engine divides by the TRUE node count; the matrix header carries the padded width
+        # the engine divides by the TRUE node count; the matrix header carries the padded width.
+        # Creating the shard may build the matrix's tiled plan on the library's stream: whatever
+        # filled the device arrays on torch's stream must be done first.
+        torch.cuda.current_stream(self.device).synchronize()
         self._shard = lib().spmv_c_pr_shard_create(self._A, self.layout.row_offset, self.layout.n,
                                                    c_void_p(mask.data_ptr()))
         if not self._shard:

@@ -307,3 +307,19 @@ def test_tiled_engine_shape_rules(spmv):
         assert w in (4096, 8192, 16384, 32768) and r % 64 == 0 and 1024 <= r <= 9984   # u16 local indices, LDS fits
         tiles = (rows + r - 1) // r
         assert tiles < 1024 or tiles % 1024 == 0 or tiles % 1024 > 900               # whole rounds of resident tiles
+
+
+def test_shard_engine_rejects_bad_arguments_without_touching_a_gpu(spmv):
+    """spmv_c_pr_shard_create validates before any device call: null matrix / mask, negative offsets and a
+    node count wider than the matrix header all give NULL (include/spmv_c.h)."""
+    import ctypes
+    lib = spmv.lib()
+    assert not lib.spmv_c_pr_shard_create(None, 0, 10, None)
+    A = spmv.csr_create(4, 4, 0)
+    mask = (ctypes.c_uint8 * 4)()
+    assert not lib.spmv_c_pr_shard_create(A, 0, 4, None)                       # no mask
+    assert not lib.spmv_c_pr_shard_create(A, -1, 4, mask)                      # negative offset
+    assert not lib.spmv_c_pr_shard_create(A, 0, 5, mask)                       # more nodes than columns
+    assert not lib.spmv_c_pr_shard_create(A, 1, 4, mask)                       # rows would run past the vector
+    assert not lib.spmv_c_pr_shard_create(A, 0, 4, mask)                       # rows but no device arrays
+    spmv.csr_destroy(A)

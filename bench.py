@@ -90,7 +90,7 @@ def main():
             dist.init_process_group(backend)
 
     # The bench matrix is column-stochastic (a_ij = 1 / outdeg(j)), a structure the tiled engine can
-    # exploit by folding the values into one weight per column (DESIGN.md §3.8).  The headline is
+    # exploit by folding the values into one weight per column (DESIGN.md §4.5).  The headline is
     # measured on the GENERAL path (value stream read per entry), so that it holds for any values;
     # the folded step is reported next to it as `pagerank_step_values_folded`.  SPMV_TILED_FOLD=1 in
     # the environment moves the headline onto the folded path (config.values_folded says which ran).

@@ -318,6 +318,11 @@ class ShardedPageRank:
                     if lib().spmv_c_ipc_open_handle(everyone[p][which], byref(opened)) != 0 or not opened.value:
                         raise RuntimeError("hipIpcOpenMemHandle refused for rank %d" % p)
                     self._peer_keepalive.append(opened.value)
+                    # read one word through the mapping with a runtime copy: a mapping this device cannot
+                    # reach comes back as an error here instead of as a fault inside a step kernel
+                    probe = ctypes.c_float(0.0)
+                    if lib().spmv_c_memcpy_d2h(ctypes.byref(probe), opened, 4) != 0:
+                        raise RuntimeError("the mapping of rank %d's vector is not readable from here" % p)
                     ptrs[which][slot] = opened.value
                     slot += 1
         except Exception as exc:                                        # noqa: BLE001 - any failure => gather mode

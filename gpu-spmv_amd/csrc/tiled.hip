@@ -989,9 +989,10 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     }
 
     if (!plan->col_weight) e = dev_alloc(&plan->a_val, plan->nnz);
-    if (e == hipSuccess) e = dev_alloc(&plan->a_lcol, plan->nnz);
-    if (e == hipSuccess) e = dev_alloc(&plan->a_lrow, plan->nnz);
-    if (e == hipSuccess) e = dev_alloc(&plan->prod, plan->nnz);
+    // + 8: the paired / 16-byte loads of a run's last group may touch a few entries past the end
+    if (e == hipSuccess) e = dev_alloc(&plan->a_lcol, plan->nnz + 8);
+    if (e == hipSuccess) e = dev_alloc(&plan->a_lrow, plan->nnz + 8);
+    if (e == hipSuccess) e = dev_alloc(&plan->prod, plan->nnz + 8);
     if (e == hipSuccess && plan->num_long > 0) {
         e = dev_alloc(&plan->seed, plan->num_rows);
         if (e == hipSuccess) e = hipMemsetAsync(plan->seed, 0, static_cast<size_t>(plan->num_rows) * sizeof(float), s);

@@ -46,31 +46,79 @@ TAIL = 4   # floats appended to every slice when world > 1 (two doubles)
 
 
 class Layout:
-    """Where node g lives in the (padded) rank vector, and who owns which rows."""
+    """Where node g lives in the (padded) rank vector, and who owns which rows.
 
-    def __init__(self, n: int, world: int = 1, rank: int = 0):
+    Rank p owns the contiguous row block [bounds[p], bounds[p + 1]).  Default: equal ROWS
+    (ceil(n / world), what a uniform matrix wants).  `bounds` (world + 1 ascending row indices, e.g. from
+    `equal_nnz_bounds`) cuts the rows anywhere — SURVEY.md §8(e): "boundaries chosen by binary search
+    on row_ptrs for equal nnz" — so that a power-law graph does not leave one rank with most of the
+    entries.  Every slice of the padded vector has the same stride (the all-gather needs equal counts):
+    stride = longest block (rounded up to even) + TAIL."""
+
+    def __init__(self, n: int, world: int = 1, rank: int = 0, bounds=None):
         self.n, self.world, self.rank = n, world, rank
-        shard_len = (n + world - 1) // world
-        if world > 1 and shard_len % 2:
-            shard_len += 1                      # keeps every tail 8-byte aligned
+        if bounds is None:
+            shard_len = (n + world - 1) // world
+            if world > 1 and shard_len % 2:
+                shard_len += 1                      # keeps every tail 8-byte aligned
+            self.bounds = np.minimum(np.arange(world + 1, dtype=np.int64) * shard_len, n)
+            self.equal_rows = True
+        else:
+            self.bounds = np.asarray(bounds, dtype=np.int64)
+            assert self.bounds.shape == (world + 1,) and self.bounds[0] == 0 and self.bounds[-1] == n
+            assert (np.diff(self.bounds) >= 0).all()
+            shard_len = int(np.diff(self.bounds).max()) if world > 0 else n
+            if world > 1 and shard_len % 2:
+                shard_len += 1
+            self.equal_rows = False
         self.shard_len = shard_len
         self.stride = shard_len + (TAIL if world > 1 else 0)
         self.padded = self.stride * world
-        self.row_begin = min(rank * shard_len, n)
-        self.row_end = min(self.row_begin + shard_len, n)
+        self.row_begin = int(self.bounds[rank])
+        self.row_end = int(self.bounds[rank + 1])
         self.local_rows = self.row_end - self.row_begin
         self.row_offset = rank * self.stride    # position of this rank's first node in the vector
+
+    @staticmethod
+    def equal_nnz_bounds(row_ptrs, world: int) -> np.ndarray:
+        """Row boundaries that give every rank about nnz / world entries: binary search on the
+        (global) row_ptrs for the targets p * nnz / world."""
+        row_ptrs = np.asarray(row_ptrs, dtype=np.int64)
+        n, nnz = len(row_ptrs) - 1, int(row_ptrs[-1])
+        targets = (np.arange(1, world, dtype=np.int64) * nnz + world // 2) // world
+        inner = np.clip(np.searchsorted(row_ptrs, targets, side="left"), 0, n)
+        # the search lands on the first boundary at or past the target; the one before may be nearer
+        before = np.maximum(inner - 1, 0)
+        nearer = np.abs(row_ptrs[before] - targets) < np.abs(row_ptrs[inner] - targets)
+        inner = np.maximum.accumulate(np.where(nearer, before, inner))
+        return np.concatenate([[0], inner, [n]]).astype(np.int64)
+
+    def owner_of(self, nodes):
+        """Owning rank of every node index (numpy or torch)."""
+        if isinstance(nodes, torch.Tensor):
+            edges = torch.as_tensor(self.bounds[1:-1], dtype=nodes.dtype, device=nodes.device)
+            return torch.bucketize(nodes, edges, right=True)
+        return np.searchsorted(self.bounds[1:-1], nodes, side="right")
 
     def remap_columns(self, cols):
         """Column (= node) indices -> positions in the padded vector (numpy or torch int32)."""
         if self.world == 1:
             return cols
-        return cols + (cols // self.shard_len) * TAIL
+        if self.equal_rows:
+            return cols + (cols // self.shard_len) * TAIL
+        owner = self.owner_of(cols)
+        if isinstance(cols, torch.Tensor):
+            begin = torch.as_tensor(self.bounds[:-1], dtype=cols.dtype, device=cols.device)[owner]
+            return (owner * self.stride).to(cols.dtype) + (cols - begin)
+        return (owner * self.stride + (cols - self.bounds[:-1][owner])).astype(cols.dtype)
 
     def positions(self) -> np.ndarray:
         """Padded position of every node 0..n-1."""
         g = np.arange(self.n, dtype=np.int64)
-        return (g // self.shard_len) * self.stride + g % self.shard_len
+        if self.world == 1:
+            return g
+        owner = np.searchsorted(self.bounds[1:-1], g, side="right")
+        return owner * self.stride + (g - self.bounds[:-1][owner])
 
     def tail_slice(self, rank=None):
         rank = self.rank if rank is None else rank

@@ -99,13 +99,20 @@ def make_graph(spmv, n, k, seed, dangling_cols=()):
     return rp, ci, va
 
 
+def make_power_law_graph(spmv, n, seed):
+    """Rows sorted by length, longest first: equal-ROW shards would hand rank 0 most of the entries."""
+    lens = np.sort(spmv.synth.power_law_lengths(seed, n, max_len=n // 2, n_cols=n))[::-1]
+    rp, ci, _ = spmv.synth.stratified_csr(seed, 0, lens, n)
+    return rp, ci, spmv.synth.column_stochastic_values(ci, n)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, k, seed, dangling, tol, max_iter, check_every, out_dir):
+def _worker(rank, world, port, n, k, seed, dangling, tol, max_iter, check_every, out_dir, power_law=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -115,8 +122,12 @@ def _worker(rank, world, port, n, k, seed, dangling, tol, max_iter, check_every,
         spmv = importlib.import_module("gpu-spmv_amd")
         prd = importlib.import_module("gpu-spmv_amd.pagerank_dist")
         oracle = importlib.import_module("oracle")
-        rp, ci, va = make_graph(spmv, n, k, seed, dangling)
-        lay = prd.Layout(n, world, rank)
+        if power_law:                       # unequal-nnz rows: boundaries by binary search on row_ptrs
+            rp, ci, va = make_power_law_graph(spmv, n, seed)
+            lay = prd.Layout(n, world, rank, bounds=prd.Layout.equal_nnz_bounds(rp, world))
+        else:
+            rp, ci, va = make_graph(spmv, n, k, seed, dangling)
+            lay = prd.Layout(n, world, rank)
         b, e = lay.row_begin, lay.row_end
         lrp = (rp[b:e + 1] - rp[b]).astype(np.int32)
         lci, lva = lay.remap_columns(ci[rp[b]:rp[e]]).astype(np.int32), va[rp[b]:rp[e]]
@@ -124,14 +135,15 @@ def _worker(rank, world, port, n, k, seed, dangling, tol, max_iter, check_every,
         pr = prd.ShardedPageRank(engine, lay).prepare()
         ranks, iters, res, conv = pr.run(0.85, tol, max_iter, check_every)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ranks=ranks, iters=iters, res=res, conv=conv,
-                 num_dangling=pr.num_dangling)
+                 num_dangling=pr.num_dangling, local_rows=lay.local_rows, local_nnz=int(lrp[-1]))
     finally:
         dist.destroy_process_group()
 
 
-def _run(world, tmp_path, n=600, k=6, seed=5, dangling=(3, 77, 401), tol=1e-6, max_iter=100, check_every=1):
+def _run(world, tmp_path, n=600, k=6, seed=5, dangling=(3, 77, 401), tol=1e-6, max_iter=100, check_every=1,
+         power_law=False):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, k, seed, dangling, tol, max_iter, check_every, str(tmp_path)),
+    mp.spawn(_worker, args=(world, port, n, k, seed, dangling, tol, max_iter, check_every, str(tmp_path), power_law),
              nprocs=world, join=True)
     return [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
 
@@ -147,8 +159,41 @@ def test_sharded_pagerank_equals_unsharded_oracle(spmv, oracle, tmp_path, world)
         np.testing.assert_array_equal(o["ranks"], outs[0]["ranks"])
         assert int(o["num_dangling"]) == int(oracle.dangling_mask(rp, ci, va, n).sum()) >= len(dangling)
         assert bool(o["conv"]) and abs(int(o["iters"]) - iters) <= 1
-        assert np.max(np.abs(o["ranks"] - want)) < 1e-6
         assert abs(float(o["ranks"].sum()) - 1.0) < 1e-4 and (o["ranks"] >= 0).all()
+    # every rank at 1e-5 RELATIVE, at equal iteration counts (a run that stops one step apart is re-run
+    # on the oracle with the sharded loop's count: tolerance 0 returns the last computed vector)
+    got_iters = int(outs[0]["iters"])
+    if got_iters != iters:
+        want, *_ = oracle.pagerank(rp, ci, va, num_cols=n, tolerance=0.0, max_iterations=got_iters, wide_sums=True)
+    assert np.max(np.abs(outs[0]["ranks"].astype(np.float64) - want) / want) <= 1e-5
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_equal_nnz_shards_on_a_power_law_graph(spmv, oracle, tmp_path, world):
+    """shard boundaries by binary search on row_ptrs for equal nnz.  Rows sorted longest
+    first, so equal-row shards would be badly unbalanced; the nnz partition gives shards of very different
+    ROW counts (the padded layout's stride = the longest), and the answer must still be the oracle's."""
+    prd = importlib.import_module("gpu-spmv_amd.pagerank_dist")
+    n, seed = 900, 11
+    rp, ci, va = make_power_law_graph(spmv, n, seed)
+    nnz = int(rp[-1])
+    rows_equal = [int(rp[min((r + 1) * ((n + world - 1) // world), n)] - rp[min(r * ((n + world - 1) // world), n)])
+                  for r in range(world)]
+    assert max(rows_equal) > 1.5 * nnz / world                      # the equal-row cut IS unbalanced here
+    bounds = prd.Layout.equal_nnz_bounds(rp, world)
+    shares = np.diff(rp[bounds])
+    assert shares.sum() == nnz and shares.max() <= nnz / world + int(np.diff(rp).max())    # within one row of even
+    outs = _run(world, tmp_path, n=n, seed=seed, power_law=True, max_iter=200)
+    assert [int(o["local_nnz"]) for o in outs] == shares.tolist()
+    assert len({int(o["local_rows"]) for o in outs}) > 1            # unequal row counts went through the layout
+    want, iters, res, conv = oracle.pagerank(rp, ci, va, num_cols=n, max_iterations=200, wide_sums=True)
+    got_iters = int(outs[0]["iters"])
+    assert bool(outs[0]["conv"]) == conv and abs(got_iters - iters) <= 1
+    if got_iters != iters:
+        want, *_ = oracle.pagerank(rp, ci, va, num_cols=n, tolerance=0.0, max_iterations=got_iters, wide_sums=True)
+    for o in outs:
+        np.testing.assert_array_equal(o["ranks"], outs[0]["ranks"])
+    assert np.max(np.abs(outs[0]["ranks"].astype(np.float64) - want) / want) <= 1e-5
 
 
 def test_running_ahead_of_the_convergence_check_changes_nothing(tmp_path):
@@ -185,5 +230,22 @@ def test_layout(spmv):
             t = lay.tail_slice(r)
             tails |= set(range(t.start, t.stop))
         assert not (tails & set(pos.tolist()))
+    # arbitrary row bounds (equal-nnz partition): positions unique, remap == positions, tails disjoint
+    for bounds in ([0, 1, 10], [0, 7, 7, 10], [0, 0, 3, 10], [0, 601, 601]):
+        n, world = bounds[-1], len(bounds) - 1
+        lay = prd.Layout(n, world, 0, bounds=bounds)
+        pos = lay.positions()
+        assert len(set(pos.tolist())) == n and pos.max() < lay.padded and lay.stride % 2 == 0
+        np.testing.assert_array_equal(lay.remap_columns(np.arange(n, dtype=np.int32)), pos)
+        np.testing.assert_array_equal(lay.remap_columns(torch.arange(n, dtype=torch.int32)).numpy(), pos)
+        tails = set()
+        for r in range(world):
+            lr = prd.Layout(n, world, r, bounds=bounds)
+            assert (lr.row_begin, lr.row_end) == (bounds[r], bounds[r + 1]) and lr.local_rows <= lr.shard_len
+            t = lay.tail_slice(r)
+            tails |= set(range(t.start, t.stop))
+        assert not (tails & set(pos.tolist()))
+    rp = np.array([0, 10, 10, 11, 12, 40, 41], dtype=np.int32)
+    np.testing.assert_array_equal(prd.Layout.equal_nnz_bounds(rp, 2), [0, 4, 6])
     assert prd.initial_dangling_mass(0, 10) == 0.0
     assert prd.initial_dangling_mass(3, 10) == float(np.float32(np.float32(np.float32(0.1) + np.float32(0.1)) + np.float32(0.1)))

@@ -1,8 +1,16 @@
 """GPU tests of the device-resident PageRank (C ABI spmv_c_pagerank + the shard engine)
 against the CPU oracle (restatement of reference src/pagerank.cu:50-153).
-Tolerance: the device accumulates the residual / dangling mass / final sum in double and
-reorders each row's SpMV sum, so ranks are compared at 1e-6 absolute (ranks are <= 1) and
-1e-5 relative; the iteration count may differ by one when the residual grazes `tolerance`."""
+
+Tolerance: EVERY rank is held to 1e-5 RELATIVE error against the oracle (every rank is at least
+0.15 / n > 0, so the relative error is defined everywhere).  The device accumulates the residual /
+dangling mass / final sum in double and reorders each row's SpMV sum, so the iteration at which the
+residual crosses `tolerance` may differ by one from the oracle's; the vectors are then compared at
+EQUAL iteration counts (both re-run with tolerance = 0 and max_iterations = the smaller count —
+the result of such a run is the last computed vector, exactly what a converged run returns).
+
+Parity caveat: src/pagerank.cu needs the CUDA runtime and cannot be built in this
+image, so `oracle_pagerank` is a restatement pinned by the reference tests' known answers (3-cycle,
+invariants) only — the numeric trajectory is "parity unpinned" beyond those."""
 import importlib
 
 import numpy as np
@@ -26,11 +34,37 @@ def graph(spmv, n, k, seed, dangling=()):
     return rp, ci, spmv.synth.column_stochastic_values(ci, n)
 
 
-def compare(got, want):
-    assert np.max(np.abs(got - want)) < 1e-6
-    big = want > 1e-4
-    if big.any():
-        assert np.max(np.abs(got[big] - want[big]) / want[big]) < 1e-5 * 10   # a few ulps of 1/n-sized ranks
+RTOL = 1e-5        # north-star tolerance, relative, on every element
+
+
+def worst_rel(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape and (want > 0).all()
+    return float(np.max(np.abs(got - want) / want))
+
+
+def compare(got, want, rtol=RTOL):
+    worst = worst_rel(got, want)
+    assert worst <= rtol, "worst relative rank error %.3g > %.1g" % (worst, rtol)
+
+
+def assert_parity(gpu, oracle, A, rp, ci, va, n, result, wide_sums=True, damping=0.85, tolerance=1e-6,
+                  max_iterations=100):
+    """`result` = gpu.pagerank(A, (damping, tolerance, max_iterations)).  Flags and iteration count
+    against the oracle (count +-1), then every rank at 1e-5 relative at equal iteration counts."""
+    want, iters, res, conv = oracle.pagerank(rp, ci, va, num_cols=n, damping=damping, tolerance=tolerance,
+                                             max_iterations=max_iterations, wide_sums=wide_sums)
+    assert result.converged == conv and abs(result.iterations - iters) <= 1
+    if result.iterations == iters:
+        compare(result.ranks, want)
+        return
+    k = min(result.iterations, iters)
+    again = gpu.pagerank(A, gpu.PageRankConfig(damping, 0.0, k))
+    assert again.iterations == k and not again.converged
+    want_k, iters_k, _, _ = oracle.pagerank(rp, ci, va, num_cols=n, damping=damping, tolerance=0.0,
+                                            max_iterations=k, wide_sums=wide_sums)
+    assert iters_k == k
+    compare(again.ranks, want_k)
 
 
 def test_three_cycle_equal_ranks(gpu):
@@ -63,11 +97,9 @@ def test_score_invariants_and_oracle_parity_small_graphs(gpu, oracle):
         gpu.csr_to_gpu(A)
         r = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
         rp, ci, va = gpu.csr_host_arrays(A)
-        want, iters, res, conv = oracle.pagerank(rp, ci, va, num_cols=n)
         assert (r.ranks >= 0).all() and abs(float(r.ranks.sum()) - 1.0) < 1e-4
         assert (not r.converged) or r.final_residual < 1e-6
-        assert r.converged == conv and abs(r.iterations - iters) <= 1
-        compare(r.ranks, want)
+        assert_parity(gpu, oracle, A, rp, ci, va, n, r, wide_sums=False)      # the reference's fp32 sequential sums
         gpu.csr_destroy(A)
     assert with_dangling >= 3
 
@@ -77,9 +109,7 @@ def test_medium_graph_with_dangling_nodes(gpu, oracle):
     rp, ci, va = graph(gpu, n, 12, 9, dangling=(5, 1000, 150_000))
     A = upload(gpu, rp, ci, va, n)
     r = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
-    want, iters, res, conv = oracle.pagerank(rp, ci, va, num_cols=n, wide_sums=True)
-    assert r.converged == conv and abs(r.iterations - iters) <= 1
-    compare(r.ranks, want)
+    assert_parity(gpu, oracle, A, rp, ci, va, n, r)
     top = gpu.pagerank_top_k(r, n, 10)                      # tests/test_pagerank.cu:81-137 (P16)
     assert all(top[i][1] >= top[i + 1][1] for i in range(9))
     assert top[0][1] == r.ranks.max()
@@ -115,9 +145,7 @@ def test_device_only_matrix_uses_device_dangling_scan(gpu, oracle):
     rp, ci, va = A.to_host()
     assert oracle.dangling_mask(rp, ci, va, n).sum() > 100
     r = gpu.pagerank(A.handle, gpu.PageRankConfig(0.85, 1e-6, 100))
-    want, iters, res, conv = oracle.pagerank(rp, ci, va, num_cols=n, wide_sums=True)
-    assert r.converged == conv and abs(r.iterations - iters) <= 1
-    compare(r.ranks, want)
+    assert_parity(gpu, oracle, A.handle, rp, ci, va, n, r)
     A.close()
 
 
@@ -130,6 +158,7 @@ def test_shard_engine_single_rank_equals_pagerank(gpu, oracle):
     rp, ci, va = graph(gpu, n, 10, 4, dangling=(7, 9))
     A = upload(gpu, rp, ci, va, n)
     direct = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
+    assert_parity(gpu, oracle, A, rp, ci, va, n, direct)
     dev = torch.device("cuda:0")
     lay = prd.Layout(n)
     eng = prd.HipEngine(torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev), lay)
@@ -186,6 +215,11 @@ def test_two_shards_on_one_gpu_equal_one_shard(gpu, oracle):
             sp.engine.commit_gathered(sp.r[(k + 1) & 1], 0.0)
         torch.testing.assert_close(news[0], news[1], rtol=0, atol=0)           # both ranks hold the same vector
         torch.testing.assert_close(news[0][shards[0]._pos], whole.r[(k + 1) & 1][whole._pos], rtol=2e-6, atol=0)
+    # ... and the oracle after the same 6 steps: every rank, 1e-5 relative (the shard vectors are not normalised)
+    want, *_ = oracle.pagerank(rp, ci, va, num_cols=n, tolerance=0.0, max_iterations=6, wide_sums=True)
+    for vec in (news[0][shards[0]._pos], whole.r[0][whole._pos]):
+        v = vec.double().cpu().numpy()
+        compare(v / v.sum(), want)
     st = [sp.engine.status() for sp in shards] + [whole.engine.status()]
     assert [x[0] for x in st] == [6, 6, 6]
     assert st[0][1] == st[1][1] and abs(st[0][1] - st[2][1]) <= 1e-12 + 1e-6 * st[2][1]
@@ -201,9 +235,11 @@ def test_pagerank_through_the_tiled_engine(gpu, oracle):
     A = upload(gpu, rp, ci, va, n)
     r = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
     assert gpu.csr_has_tiled_plan(A)
-    want, iters, res, conv = oracle.pagerank(rp, ci, va, num_cols=n, wide_sums=True)
-    assert r.converged == conv and abs(r.iterations - iters) <= 1
-    compare(r.ranks, want)
+    assert_parity(gpu, oracle, A, rp, ci, va, n, r)
+    # and a fixed number of steps (no convergence test in the way): every rank, 1e-5 relative
+    fixed = gpu.pagerank(A, gpu.PageRankConfig(0.85, 0.0, 4))
+    want4, *_ = oracle.pagerank(rp, ci, va, num_cols=n, tolerance=0.0, max_iterations=4, wide_sums=True)
+    compare(fixed.ranks, want4)
     gpu.csr_destroy(A)
 
 
@@ -221,10 +257,8 @@ def test_repeated_calls_on_a_power_law_graph_with_long_rows(gpu, oracle):
     info = gpu.csr_tiled_info(A)
     assert info is not None and info["long_rows"] > 2048                   # both long-row paths are in use
     second = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
-    want, iters, res, conv = oracle.pagerank(rp, ci, va, num_cols=n, wide_sums=True)
     for r in (first, second):
-        assert r.converged == conv and abs(r.iterations - iters) <= 1
-        compare(r.ranks, want)
+        assert_parity(gpu, oracle, A, rp, ci, va, n, r)
     x = np.abs(gpu.synth.vector(31, 2, n)) + np.float32(0.01)
     d_x, d_y = gpu.CudaBuffer(n), gpu.CudaBuffer(n)
     d_x.copyFromHost(x, n)
@@ -235,11 +269,14 @@ def test_repeated_calls_on_a_power_law_graph_with_long_rows(gpu, oracle):
     gpu.csr_destroy(A)
 
 
-def test_config5_pagerank_full_size_invariants(gpu):
-    """BASELINE config 5: PageRank (d = 0.85, tol = 1e-6) on the 10 M-node / 160 M-edge
-    column-stochastic matrix built in HBM.  Size-independent properties (reference
-    tests/test_pagerank.cu:18-77): ranks >= 0, sum = 1 (1e-4), converged => residual < tol;
-    plus a fixed-point check: one more device SpMV step leaves the ranks in place."""
+def test_config5_pagerank_full_size_against_the_oracle(gpu, oracle):
+    """BASELINE config 5: PageRank (d = 0.85, tol = 1e-6) on the 10 M-node / 160 M-edge column-stochastic
+    matrix built in HBM.  (1) the reference's size-independent properties (tests/test_pagerank.cu:18-77):
+    ranks >= 0, sum = 1 (1e-4), converged => residual < tol; (2) the ORACLE on the full matrix for a fixed
+    number of steps (tolerance 0, k = 2: no convergence test in the way), every one of the 10 M ranks at
+    1e-5 relative — once through the value-folded plan pagerank() picks for this matrix, once through the
+    general (value stream) plan (SPMV_TILED_FOLD=0), which is the path bench.py quotes."""
+    import os
     wl = importlib.import_module("gpu-spmv_amd.workloads")
     n = 10_000_000
     A = wl.uniform_csr_device(42, n, n, 16)
@@ -247,15 +284,35 @@ def test_config5_pagerank_full_size_invariants(gpu):
     r = gpu.pagerank(A.handle, gpu.PageRankConfig(0.85, 1e-6, 100))
     assert r.converged and r.final_residual < 1e-6 and 2 <= r.iterations <= 100
     assert (r.ranks >= 0).all() and abs(float(r.ranks.sum(dtype=np.float64)) - 1.0) < 1e-4
-    # fixed point: r ~ d * A r + (1 - d) / n + d * dangling_mass / n; all terms from the device SpMV
-    d_r, d_y = gpu.CudaBuffer(n), gpu.CudaBuffer(n)
-    d_r.copyFromHost(r.ranks, n)
-    assert gpu.spmv_csr(A.handle, d_r, d_y, gpu.SpMVConfig(1, 256, True), n).error_code == 0
-    y = d_y.copyToHost(n).astype(np.float64)
-    counts = np.bincount(A.col_indices.copyToHost(A.nnz), minlength=n)
-    dangling = float(r.ranks[counts == 0].sum(dtype=np.float64))
-    nxt = 0.85 * y + 0.85 * dangling / n + 0.15 / n
-    assert np.sqrt(np.sum((nxt - r.ranks) ** 2)) < 5e-6
+    info = gpu.csr_tiled_info(A.handle)
+    assert info is not None and info.get("values_folded")
+
+    rp, ci, va = A.to_host()
+    k = 2
+    want, iters, _, _ = oracle.pagerank(rp, ci, va, num_cols=n, tolerance=0.0, max_iterations=k, wide_sums=True)
+    assert iters == k
+    fixed = gpu.pagerank(A.handle, gpu.PageRankConfig(0.85, 0.0, k))
+    assert fixed.iterations == k
+    compare(fixed.ranks, want)                                        # folded plan
+    # the converged run, too: the oracle converges on this matrix within a handful of steps
+    want_c, iters_c, _, conv_c = oracle.pagerank(rp, ci, va, num_cols=n, wide_sums=True)
+    assert conv_c and abs(iters_c - r.iterations) <= 1
+    if iters_c == r.iterations:
+        compare(r.ranks, want_c)
+
+    previous = os.environ.get("SPMV_TILED_FOLD")
+    os.environ["SPMV_TILED_FOLD"] = "0"
+    try:
+        gpu.csr_invalidate_gpu_cache(A.handle)                        # drop the folded plan; the next call rebuilds
+        general = gpu.pagerank(A.handle, gpu.PageRankConfig(0.85, 0.0, k))
+        info = gpu.csr_tiled_info(A.handle)
+        assert info is not None and not info.get("values_folded")
+        compare(general.ranks, want)                                  # general plan
+    finally:
+        if previous is None:
+            del os.environ["SPMV_TILED_FOLD"]
+        else:
+            os.environ["SPMV_TILED_FOLD"] = previous
     A.close()
 
 
@@ -302,6 +359,9 @@ def test_push_exchange_two_shards_on_one_gpu(gpu, oracle):
         a, b = shards[0].r[(k + 1) & 1][shards[0]._pos], shards[1].r[(k + 1) & 1][shards[1]._pos]
         torch.testing.assert_close(a, b, rtol=0, atol=0)
         torch.testing.assert_close(a, whole.r[(k + 1) & 1][whole._pos], rtol=2e-6, atol=0)
+    want, *_ = oracle.pagerank(rp, ci, va, num_cols=n, tolerance=0.0, max_iterations=5, wide_sums=True)
+    v = a.double().cpu().numpy()
+    compare(v / v.sum(), want)                                   # the pushed vector against the oracle, every rank
     assert shards[0].engine.status()[0] == shards[1].engine.status()[0] == whole.engine.status()[0] == 5
     for sp in shards + [whole]:
         sp.engine.close()

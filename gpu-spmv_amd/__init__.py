@@ -186,6 +186,7 @@ _SIGNATURES = {
     "spmv_c_csr_has_tiled_plan": (c_int, [POINTER(CSRMatrix)]),
     "spmv_c_tiled_shape": (c_int, [c_int64, c_int64, c_int64, POINTER(c_int32), POINTER(c_int32)]),
     "spmv_c_csr_tiled_info": (c_int, [POINTER(CSRMatrix), POINTER(c_int64)]),
+    "spmv_c_csr_tiled_stats": (c_int, [POINTER(CSRMatrix), POINTER(c_double)]),
     "spmv_c_csr_tiled_folded": (c_int, [POINTER(CSRMatrix)]),
     "spmv_c_spmv_csr_async": (c_int, [POINTER(CSRMatrix), c_void_p, c_void_p, POINTER(SpMVConfig), c_int,
                                       c_void_p]),
@@ -613,10 +614,15 @@ def csr_tiled_info(A):
     out = (c_int64 * 8)()
     if not lib().spmv_c_csr_tiled_info(A, out):
         return None
-    keys = ("strip_cols", "tile_rows", "num_strips", "num_tiles", "entries_in_cells", "long_rows",
-            "chunks_per_pass", "long_row_limit")
+    keys = ("strip_cols", "tile_rows", "num_strips", "num_tiles", "slots_in_cells", "long_rows",
+            "slots_per_lane", "long_row_limit")
     info = dict(zip(keys, (int(v) for v in out)))
     info["values_folded"] = bool(lib().spmv_c_csr_tiled_folded(A))
+    stats = (c_double * 4)()
+    if lib().spmv_c_csr_tiled_stats(A, stats):
+        info["build_ms"] = round(float(stats[0]), 3)
+        info["plan_bytes"] = int(stats[1])
+        info["entries_in_cells"] = int(stats[3])
     return info
 
 

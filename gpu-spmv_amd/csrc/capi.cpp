@@ -302,9 +302,22 @@ int spmv_c_csr_tiled_info(const spmv_c_csr* A_c, int64_t out[8]) {
     detail::CsrAux* aux = detail::aux_lookup(A->d_row_ptrs, false);
     if (!aux || !aux->tiled) return 0;
     const detail::TiledPlan& p = *aux->tiled;
-    const int64_t v[8] = {p.strip_cols, p.tile_rows, p.num_strips, p.num_tiles, p.nnz, p.num_long, p.run_chunks,
+    const int64_t v[8] = {p.strip_cols, p.tile_rows, p.num_strips, p.num_tiles, p.nnz, p.num_long, p.lane_entries,
                           p.long_row};
     std::memcpy(out, v, sizeof(v));
+    return 1;
+}
+
+int spmv_c_csr_tiled_stats(const spmv_c_csr* A_c, double out[4]) {
+    const CSRMatrix* A = cxx(A_c);
+    if (!A || !A->d_row_ptrs || !out) return 0;
+    detail::CsrAux* aux = detail::aux_lookup(A->d_row_ptrs, false);
+    if (!aux || !aux->tiled) return 0;
+    const detail::TiledPlan& p = *aux->tiled;
+    out[0] = p.build_ms;
+    out[1] = static_cast<double>(p.plan_bytes);
+    out[2] = static_cast<double>(p.nnz);
+    out[3] = static_cast<double>(p.entries);
     return 1;
 }
 

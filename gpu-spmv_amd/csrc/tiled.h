@@ -18,26 +18,28 @@ struct PushTargets;
 // side table, dropped by csr_free_gpu).
 struct TiledPlan {
     int num_rows = 0, num_cols = 0;
-    long long nnz = 0;              // entries held in cells (short rows only)
+    long long nnz = 0;              // SLOTS held in cells: the short rows' entries + row-skip markers + padding
+    long long entries = 0;          // of which real matrix entries
     int strip_cols = 0;             // W: x columns per LDS strip
     int tile_rows = 0;              // R: y rows per LDS tile
     int num_strips = 0, num_tiles = 0;
-    int run_chunks = 2;             // 64-entry chunks read from a run per phase-2 pass (1, 2 or 4)
+    int lane_entries = 4;           // slots per lane per phase-2 load (2 for short runs, else 4)
 
-    // entries sorted by cell (strip-major, tile inside a strip)
+    // slots sorted by cell (strip-major, tile inside a strip); inside a cell by (row, column).
+    // Every cell's length is a multiple of 4 slots.
     float*    a_val = nullptr;      // [nnz]; null when the values are folded into col_weight
     float*    col_weight = nullptr; // [num_cols] the one value every entry of a column carries, or null
     uint16_t* a_lcol = nullptr;     // [nnz] column - strip * W
-    uint16_t* a_lrow = nullptr;     // [nnz] row - tile * R
+    uint8_t*  a_drow = nullptr;     // [nnz] row - (row of the cell's previous slot), 0..254; 255 = advance 255 rows, no entry
     float*    prod = nullptr;       // [nnz] phase-1 output / phase-2 input, same order
     int*      cells_t = nullptr;    // [2 * num_tiles * num_strips]: (begin, length) pairs, tile-major
 
-    // phase-1 work items: (strip, begin, end), at most kItemEntries entries each
+    // phase-1 work items: (strip, begin, end), at most kItemEntries slots each
     int* items = nullptr;           // [3 * num_items]
     int  num_items = 0;
 
-    // rows longer than kLongRow: summed by one wavefront each from the CSR arrays
-    int*   long_rows = nullptr;     // [num_long]
+    // rows longer than long_row: summed by one wavefront per 512-entry chunk from the CSR arrays
+    int*   long_rows = nullptr;     // [num_long] ascending
     int    num_long = 0;
     int    long_row = 1024;         // rows with more entries than this are "long"
     int*   long_chunks = nullptr;   // [3 * num_long_chunks] (row, begin, end) over the CSR arrays
@@ -47,6 +49,10 @@ struct TiledPlan {
     const int*   csr_cols = nullptr;
     const float* csr_vals = nullptr;
     long long    csr_nnz = 0;
+
+    // what the build cost (reported by bench.py)
+    double    build_ms = 0.0;       // host wall clock of the build, allocations and syncs included
+    long long plan_bytes = 0;       // device memory the plan holds
 };
 
 // the (strip columns, tile rows) the engine would pick for a matrix of this shape, and whether it
@@ -57,7 +63,7 @@ bool tiled_shape_for(long long rows, long long cols, long long nnz, int* strip_c
 bool tiled_eligible(const CSRMatrix* A);
 bool tiled_eligible(const ELLMatrix* A);
 
-// builds the plan for A's device arrays (synchronises the stream once)
+// builds the plan for A's device arrays (synchronises the stream a few times)
 hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s);
 hipError_t tiled_build(const ELLMatrix* A, TiledPlan** out, hipStream_t s);   // from the ELL slabs (no long-row path)
 void tiled_free(TiledPlan* plan);

@@ -10,29 +10,37 @@
 // enough to amortise loading its strip.  The engine therefore runs y = A x in two
 // streaming phases over a bucketed copy of the entries (propagation blocking):
 //
-//   layout : entries sorted by cell = (column strip, row tile), strip-major; per entry
-//        value f32, local column u16, local row u16 (8 B, as CSR's 8 B) + a product slot.
+//   layout : slots sorted by cell = (column strip, row tile), strip-major, and by (row, column)
+//        inside a cell.  Per slot: value f32, local column u16, ROW DELTA u8 (row minus the row of the
+//        cell's previous slot; 255 = "advance 255 rows, no entry" for the rare larger gaps) — 7 B
+//        against CSR's 8 — plus a 4-byte product slot.  Cells are padded to a multiple of 4 slots.
 //   phase 1 "expand" : a workgroup loads one x strip (W = 4 K .. 32 K columns, chosen per
-//        matrix = 16 .. 128 KiB) into LDS, streams its share of the strip's entries (value, local column) with
+//        matrix = 16 .. 128 KiB) into LDS, streams its share of the strip's slots (value, local column) with
 //        16-byte loads, gathers x from LDS and stores the products — same order, so
 //        loads and stores are all contiguous.
 //   phase 2 "reduce" : a workgroup owns one row tile (R rows in dynamic LDS, R a multiple of 64
 //        up to 9984 = 39 KiB, stretched so that the tiles fill whole rounds of resident workgroups).
-//        The tile's entries are one contiguous run per strip (cell table); the waves
-//        walk the runs, add each product into the LDS tile and finally write the tile
+//        The tile's slots are one contiguous run per strip (cell table); a wavefront takes a run,
+//        loads 4 products (16 B) + 4 row deltas (4 B) per lane, rebuilds the rows with an in-lane prefix
+//        and one DPP wavefront scan, adds each product into the LDS tile and finally the tile is written
 //        out with coalesced stores (optionally through the fused PageRank update).
 //        gfx950's ds_add_f32 is ~30x slower than its integer LDS atomics (0.38 vs 11.7
 //        lanes/clk/CU measured), so the add is a compare-and-swap on the word's integer
 //        image (3.5 lanes/clk/CU measured; race-free for any row multiplicity).
 //   folding : when every stored entry of a column has the same bits, the value stream is dropped
-//        and phase 1 gathers w_j * x_j from LDS (column_weight_probe_kernel, FOLD instantiation).
+//        and phase 1 gathers w_j * x_j from LDS (strip_weight_kernel, FOLD instantiation).
 //   both phases walk their work lists in per-XCD contiguous slices (xcd_contiguous).
 //   long rows (more than min(2048, 2 or 4 entries per strip)) would make many lanes fight over one
 //        LDS word; they are left out of the cells and summed in 512-entry chunks by extra
 //        wavefronts of the phase-1 grid (direct gather) into a side vector that seeds the tiles.
+//   build : two passes of one kernel over batches of <= ~5.5 K entries (rows of ONE tile): the batch is
+//        binned by strip in LDS, ranked inside every bin by (row, column), and — second pass — written
+//        to its cells at offsets fixed by a scan over (strip, tile, batch) counts.  No global atomics,
+//        so the layout is a pure function of the matrix (reproducible), and a cell's slots leave the
+//        workgroup as contiguous segments.
 //
-// HBM traffic per entry: 6 B read + 4 B written in phase 1, 6 B read in phase 2
-// (16 B vs CSR's 8 B) — but all of it is streamed, which beats one 64-byte random
+// HBM traffic per entry: 6 B read + 4 B written in phase 1, 5 B read in phase 2
+// (15 B vs CSR's 8 B) — but all of it is streamed, which beats one 64-byte random
 // fetch per entry by a wide margin once x leaves L2.
 // The order in which a row's products are added depends on scheduling, so the low
 // bits of y may differ from run to run (as with any atomic accumulation; the
@@ -44,6 +52,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <vector>
 
@@ -64,192 +73,550 @@ constexpr int kMaxLongRow = 2048;     // rows longer than min(this, 2 or 4 entri
 constexpr int kLongChunk = 512;       // entries per wavefront of the long-row path
 constexpr long long kMaxCells = 1LL << 26;
 constexpr long long kTargetRun = 128;        // wanted mean entries per cell (run length seen by phase 2)
-constexpr long long kResidentTiles = 1024;   // phase-2 workgroups resident at once: 256 CUs x 4 (32 wavefronts / 8)
-constexpr int kMaxTileRows = 9984;           // 4 tiles of this height (+ the reduction scratch) fit one CU's 160 KiB
+constexpr long long kResidentTiles = 512;    // phase-2 workgroups resident at once: 256 CUs x 2 (a tile of doubles is <= 78 KiB)
+constexpr int kMaxTileRows = 9984;           // 2 tiles of this many doubles (+ the reduction scratch) fit one CU's 160 KiB
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each XCD has its
+// own L2).  Both phases hand every XCD a CONTIGUOUS range of the work list, walked in order:
+// neighbours in the list then run on one XCD at about the same time and share what they both
+// touch through its L2 — the x strip of consecutive phase-1 items, the 128-byte lines that
+// adjacent runs of neighbouring tiles straddle in phase 2.  Returns -1 for the padding blocks of a
+// grid rounded up to a multiple of 8.  (Speed only: correctness never depends on placement.
+// Measured against the plain order on one box: C2 59.1 -> 55.0 us, C5 535.5 -> 530.1 us, 1/8 shard 84.5 -> 85.2 us.)
+constexpr int kXcds = 8;
+__device__ __forceinline__ int xcd_contiguous(int block, int count) {
+    const int per_xcd = (count + kXcds - 1) / kXcds;
+    const int which = (block % kXcds) * per_xcd + block / kXcds;
+    return block / kXcds < per_xcd && which < count ? which : -1;
+}
+__host__ inline int xcd_grid(int count) { return (count + kXcds - 1) / kXcds * kXcds; }
+
 // ------------------------------------------------------------------ plan building ----
-// LANES lanes walk one row; every entry of a short row is assigned to cell (strip, tile).
-// PASS 0 counts (and lists the long rows), PASS 1 scatters.
-template <int LANES, int PASS>
-__global__ __launch_bounds__(kBlock)
-void bucket_kernel(int num_rows, int num_tiles, int strip_cols, int tile_rows, int long_row,
-                   const int* __restrict__ row_ptrs, const int* __restrict__ cols,
-                   const float* __restrict__ vals,
-                   int* __restrict__ cell_counter,            // [num_strips * num_tiles]
-                   const int* __restrict__ offs,              // strip-major exclusive scan
-                   float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
-                   unsigned short* __restrict__ a_lrow,
-                   int* __restrict__ long_rows, int* __restrict__ num_long) {
-    constexpr int kRowsPerBlock = kBlock / LANES;
-    const int lane = threadIdx.x % LANES;
-    const long long row = static_cast<long long>(blockIdx.x) * kRowsPerBlock + threadIdx.x / LANES;
-    if (row >= num_rows) return;
-    const int begin = row_ptrs[row], end = row_ptrs[row + 1];
-    if (end - begin > long_row) {
-        if (PASS == 0 && lane == 0) long_rows[atomicAdd(num_long, 1)] = static_cast<int>(row);
-        return;
-    }
-    const int tile = static_cast<int>(row / tile_rows);
-    const unsigned short lrow = static_cast<unsigned short>(row % tile_rows);
-    for (int j = begin + lane; j < end; j += LANES) {
-        const int c = cols[j];
-        const int strip = c / strip_cols;
-        const long long cell = static_cast<long long>(strip) * num_tiles + tile;
-        if (PASS == 0) {
-            atomicAdd(&cell_counter[cell], 1);
-        } else {
-            const int at = offs[cell] + atomicAdd(&cell_counter[cell], 1);
-            if (a_val) a_val[at] = vals[j];
-            a_lcol[at] = static_cast<unsigned short>(c - strip * strip_cols);
-            a_lrow[at] = lrow;
+constexpr int kSkip = 255;                  // row-delta byte: advance 255 rows, no entry
+constexpr int kBuildBlock = 512;            // threads of a builder workgroup
+constexpr int kBuildLdsSmall = 72 * 1024;   // dynamic LDS of a builder workgroup (two per CU) ...
+constexpr int kBuildLdsLarge = 150 * 1024;  // ... or one per CU when the strips are many
+constexpr int kBuildBinWords = 5;           // LDS ints per strip: start, cursor, escapes, first|last, spare
+constexpr int kBuildEntryBytes = 14;        // LDS bytes per entry: key 4, value 4, bin 2, rank 2, markers|delta 2
+constexpr int kMaxBuildStrips = 3072;
+
+// where the entries come from.  offset(row) = index of the row's first entry in a virtual row-major
+// numbering; col() < 0 marks ELL padding.
+struct CsrSource {
+    const int* row_ptrs;
+    const int* cols;
+    const float* vals;
+    __device__ __forceinline__ long long offset(int row) const { return row_ptrs[row]; }
+    __device__ __forceinline__ int col(long long j) const { return cols[j]; }
+    __device__ __forceinline__ float val(long long j) const { return vals[j]; }
+    // the row in [lo, hi) that holds entry j (offset(lo) <= j < offset(hi))
+    __device__ __forceinline__ int row_of(long long j, int lo, int hi) const {
+        while (hi - lo > 1) {
+            const int mid = lo + (hi - lo) / 2;
+            if (row_ptrs[mid] <= j) lo = mid; else hi = mid;
         }
+        return lo;
     }
+};
+struct EllSource {
+    int rows, width;
+    const int* cols;
+    const float* vals;
+    __device__ __forceinline__ long long offset(int row) const { return static_cast<long long>(row) * width; }
+    __device__ __forceinline__ long long slot(long long j, int row) const {
+        return (j - static_cast<long long>(row) * width) * rows + row;
+    }
+    __device__ __forceinline__ int row_of(long long j, int, int) const { return static_cast<int>(j / width); }
+    __device__ __forceinline__ int col(long long j) const { return cols[slot(j, row_of(j, 0, 0))]; }
+    __device__ __forceinline__ float val(long long j) const { return vals[slot(j, row_of(j, 0, 0))]; }
+};
+
+struct BuildShape {
+    int num_rows, num_tiles, num_strips, strip_shift, tile_rows, long_row;
+    int any_long;               // some row is longer than long_row (then every entry's row length is checked)
+    long long quota;            // entries per batch before the next one starts
+};
+
+// longest row (capped by the caller): sizes the batches
+template <typename Src>
+__global__ __launch_bounds__(kBlock)
+void max_row_kernel(Src src, int num_rows, int* __restrict__ out) {
+    int best = 0;
+    for (long long r = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; r < num_rows;
+         r += static_cast<long long>(gridDim.x) * kBlock) {
+        best = max(best, static_cast<int>(src.offset(static_cast<int>(r) + 1) - src.offset(static_cast<int>(r))));
+    }
+    for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+    if ((threadIdx.x & 63) == 0 && best > 0) atomicMax(out, best);
 }
 
-// The same two passes with the cell counters aggregated in LDS: a workgroup takes a block of
-// rows inside ONE tile, so its entries differ only in the strip; it counts them per strip in LDS
-// and touches each global cell counter once (pass 0: add the count; pass 1: reserve a range and
-// hand out its slots from an LDS cursor).  Global atomics are device-scope round trips (~21 G/s
-// chip-wide, 160 M of them = 7.7 ms on C5); this way there are num_strips per workgroup instead
-// of one per entry.  Dynamic LDS: num_strips ints in pass 0, twice that in pass 1.
-template <int LANES, int PASS>
+// batches per tile: a tile's rows are cut wherever the running entry count passes a multiple of quota
+template <typename Src>
 __global__ __launch_bounds__(kBlock)
-void bucket_lds_kernel(int num_rows, int num_tiles, int num_strips, int strip_cols, int tile_rows, int long_row,
-                       int rows_per_block, int blocks_per_tile,
-                       const int* __restrict__ row_ptrs, const int* __restrict__ cols,
-                       const float* __restrict__ vals,
-                       int* __restrict__ cell_counter, const int* __restrict__ offs,
+void tile_batches_kernel(Src src, BuildShape sh, int* __restrict__ count) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= sh.num_tiles) return;
+    const int r0 = static_cast<int>(min(static_cast<long long>(t) * sh.tile_rows, static_cast<long long>(sh.num_rows)));
+    const int r1 = static_cast<int>(min(static_cast<long long>(r0) + sh.tile_rows, static_cast<long long>(sh.num_rows)));
+    const long long entries = src.offset(r1) - src.offset(r0);
+    count[t] = static_cast<int>(max(1LL, (entries + sh.quota - 1) / sh.quota));
+}
+
+// first row of every batch (binary search for the batch's entry offset inside its tile)
+template <typename Src>
+__global__ __launch_bounds__(kBlock)
+void batch_rows_kernel(Src src, BuildShape sh, const int* __restrict__ tile_batch /*[tiles + 1]*/,
+                       int* __restrict__ batch_row /*[batches + 1]*/, int* __restrict__ batch_tile) {
+    const int t = blockIdx.x;
+    const int r0 = static_cast<int>(min(static_cast<long long>(t) * sh.tile_rows, static_cast<long long>(sh.num_rows)));
+    const int r1 = static_cast<int>(min(static_cast<long long>(r0) + sh.tile_rows, static_cast<long long>(sh.num_rows)));
+    const long long origin = src.offset(r0);
+    const int first = tile_batch[t], n = tile_batch[t + 1] - first;
+    for (int b = threadIdx.x; b < n; b += kBlock) {
+        const long long target = origin + static_cast<long long>(b) * sh.quota;
+        int lo = r0, hi = r1;                         // first row whose offset >= target
+        while (lo < hi) {
+            const int mid = lo + (hi - lo) / 2;
+            if (src.offset(mid) >= target) hi = mid; else lo = mid + 1;
+        }
+        batch_row[first + b] = lo;
+        batch_tile[first + b] = t;
+    }
+    if (t == sh.num_tiles - 1 && threadIdx.x == 0) batch_row[tile_batch[sh.num_tiles]] = sh.num_rows;
+}
+
+// per (batch, strip) group: what pass 0 learns / what pass 1 needs (same 8-byte slot)
+struct GroupCount { unsigned short count, first, last, escapes; };      // escapes: inside the group only
+struct GroupPlace { unsigned int rel; unsigned short prev_last, unused; };   // rel: offset inside the cell
+static_assert(sizeof(GroupCount) == 8 && sizeof(GroupPlace) == 8, "group records share storage");
+
+// One batch (consecutive rows of one tile, at most `capacity` short-row entries): bin the entries by strip
+// in LDS, rank every entry inside its bin by (row, column), derive the row deltas and the skip markers
+// they need.  PASS 0 reports each bin's size; PASS 1 writes the slots to their cells.
+// Dynamic LDS: kBuildBinWords ints per strip, then per entry key u32, value f32, bin u16, rank u16, markers|delta u16.
+template <typename Src, int PASS>
+__global__ __launch_bounds__(kBuildBlock)
+void batch_sort_kernel(Src src, BuildShape sh, int num_batches, int capacity,
+                       const int* __restrict__ batch_row, const int* __restrict__ batch_tile,
+                       uint2* __restrict__ groups,                 // [batches * strips] GroupCount / GroupPlace
+                       const int* __restrict__ offs,               // PASS 1: cell begins, strip-major
                        float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
-                       unsigned short* __restrict__ a_lrow,
+                       unsigned char* __restrict__ a_drow,
                        int* __restrict__ long_rows, int* __restrict__ num_long) {
-    extern __shared__ int bucket_lds[];
-    int* hist = bucket_lds;
-    int* cursor = bucket_lds + num_strips;                 // pass 1 only
-    const int tile = blockIdx.x / blocks_per_tile;
-    const long long tile_first = static_cast<long long>(tile) * tile_rows;
-    const long long row0 = tile_first + static_cast<long long>(blockIdx.x % blocks_per_tile) * rows_per_block;
-    const long long row1 = min(min(row0 + rows_per_block, tile_first + tile_rows), static_cast<long long>(num_rows));
-    for (int i = threadIdx.x; i < num_strips; i += kBlock) hist[i] = 0;
+    extern __shared__ int build_lds[];
+    __shared__ int s_partial[kBuildBlock];
+    __shared__ int s_overflow;
+    const int batch = xcd_contiguous(blockIdx.x, num_batches);
+    if (batch < 0) return;
+    const int S = sh.num_strips;
+    int* bin_start = build_lds;                 // [S] first slot of the bin (after the scan)
+    int* bin_cursor = build_lds + S;            // [S] histogram, then fill cursor (= bin end once filled)
+    int* bin_escapes = build_lds + 2 * S;       // [S] skip markers needed inside the bin
+    int* bin_ends = build_lds + 3 * S;          // [S] first lrow << 16 | last lrow
+    unsigned int* keys = reinterpret_cast<unsigned int*>(build_lds + kBuildBinWords * S);    // lrow << 16 | lcol
+    float* vals = reinterpret_cast<float*>(keys + capacity);
+    unsigned short* bin_of = reinterpret_cast<unsigned short*>(vals + capacity);
+    unsigned short* rank_of = bin_of + capacity;          // PASS 1: rank inside the bin
+    unsigned short* need_delta = rank_of + capacity;      // PASS 1: markers in front << 8 | row delta
+
+    const int tile = batch_tile[batch];
+    const int row0 = batch_row[batch];
+    // the next batch starts where this one ends — unless it belongs to the next tile
+    const long long tile_end = min(static_cast<long long>(tile + 1) * sh.tile_rows, static_cast<long long>(sh.num_rows));
+    const int row1 = batch + 1 < num_batches && batch_tile[batch + 1] == tile ? batch_row[batch + 1]
+                                                                                : static_cast<int>(tile_end);
+    const int tile_first = tile * sh.tile_rows;
+
+    for (int i = threadIdx.x; i < S; i += kBuildBlock) {
+        bin_cursor[i] = 0;
+        bin_escapes[i] = 0;
+        bin_ends[i] = 0;
+    }
+    if (threadIdx.x == 0) s_overflow = 0;
     __syncthreads();
 
-    constexpr int kRowsPerSweep = kBlock / LANES;
-    const int lane = threadIdx.x % LANES;
-    for (long long row = row0 + threadIdx.x / LANES; row < row1; row += kRowsPerSweep) {
-        const int begin = row_ptrs[row], end = row_ptrs[row + 1];
-        if (end - begin > long_row) {
-            if (PASS == 0 && lane == 0) long_rows[atomicAdd(num_long, 1)] = static_cast<int>(row);
-            continue;
+    // Every short-row entry of the batch, flat over the batch's entry range: coalesced loads, four in
+    // flight per thread.  The entry's row is looked up only where it is needed.
+    const long long entry0 = src.offset(row0), entry1 = src.offset(row1);
+    auto for_each_entry = [&](auto&& body) {
+        for (long long j0 = entry0 + threadIdx.x; j0 < entry1; j0 += 4 * kBuildBlock) {
+            int c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long j = j0 + static_cast<long long>(u) * kBuildBlock;
+                c[u] = j < entry1 ? src.col(j) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c[u] >= 0) body(j0 + static_cast<long long>(u) * kBuildBlock, c[u]);
+            }
         }
-        for (int j = begin + lane; j < end; j += LANES) atomicAdd(&hist[cols[j] / strip_cols], 1);
+    };
+    // -1 for an entry of a long row (PASS 0 also lists the row, once, at its first entry)
+    auto short_row_of = [&](long long j) {
+        const int row = src.row_of(j, row0, row1);
+        if (!sh.any_long) return row;
+        const long long begin = src.offset(row);
+        if (src.offset(row + 1) - begin <= sh.long_row) return row;
+        if (PASS == 0 && j == begin) long_rows[atomicAdd(num_long, 1)] = row;
+        return -1;
+    };
+
+    // ---- histogram of the batch's short-row entries over the strips
+    for_each_entry([&](long long j, int c) {
+        if (sh.any_long && short_row_of(j) < 0) return;
+        atomicAdd(&bin_cursor[c >> sh.strip_shift], 1);
+    });
+    __syncthreads();
+
+    // ---- exclusive scan of the histogram: every thread owns a contiguous piece of the strips
+    {
+        const int per = (S + kBuildBlock - 1) / kBuildBlock;
+        const int lo = min(S, per * static_cast<int>(threadIdx.x)), hi = min(S, lo + per);
+        int sum = 0;
+        for (int i = lo; i < hi; ++i) sum += bin_cursor[i];
+        s_partial[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = 1; off < kBuildBlock; off <<= 1) {
+            const int add = static_cast<int>(threadIdx.x) >= off ? s_partial[threadIdx.x - off] : 0;
+            __syncthreads();
+            s_partial[threadIdx.x] += add;
+            __syncthreads();
+        }
+        int run = threadIdx.x ? s_partial[threadIdx.x - 1] : 0;
+        for (int i = lo; i < hi; ++i) {
+            const int n = bin_cursor[i];
+            bin_start[i] = run;
+            bin_cursor[i] = run;
+            run += n;
+        }
+        if (threadIdx.x == kBuildBlock - 1 && s_partial[kBuildBlock - 1] > capacity) s_overflow = 1;
     }
     __syncthreads();
-    if (PASS == 0) {
-        for (int i = threadIdx.x; i < num_strips; i += kBlock) {
-            if (hist[i]) atomicAdd(&cell_counter[static_cast<long long>(i) * num_tiles + tile], hist[i]);
+    if (s_overflow) return;          // cannot happen (the batch quota bounds the count); never write past LDS
+    const int total = s_partial[kBuildBlock - 1];
+
+    // ---- fill the bins (order inside a bin is arbitrary here; the ranking below fixes it)
+    for_each_entry([&](long long j, int c) {
+        const int row = PASS == 0 && sh.any_long ? src.row_of(j, row0, row1) : short_row_of(j);
+        if (sh.any_long) {
+            if (PASS == 0) {       // (the histogram pass has listed the long rows already)
+                if (src.offset(row + 1) - src.offset(row) > sh.long_row) return;
+            } else if (row < 0) {
+                return;
+            }
         }
+        const unsigned int lrow = static_cast<unsigned int>(row - tile_first);
+        const int strip = c >> sh.strip_shift;
+        const int u = atomicAdd(&bin_cursor[strip], 1);
+        keys[u] = (lrow << 16) | static_cast<unsigned int>(c - (strip << sh.strip_shift));
+        bin_of[u] = static_cast<unsigned short>(strip);
+        if (PASS == 1) vals[u] = src.val(j);
+    });
+    __syncthreads();
+
+    // ---- rank inside the bin = number of slots ordered before this one; the largest key among them is the
+    //      predecessor's.  Order: (row, column); a row that stores one column twice (legal CSR) is ordered by
+    //      the value bits next, so the layout stays a function of the matrix; fully identical entries — and
+    //      PASS 0, which needs counts only — fall back on the slot index.
+    auto before = [&](int v, unsigned int key_v, int u, unsigned int key_u) {
+        if (key_v != key_u) return key_v < key_u;
+        if (PASS == 1) {
+            const unsigned int a = __float_as_uint(vals[v]), b = __float_as_uint(vals[u]);
+            if (a != b) return a < b;
+        }
+        return v < u;
+    };
+    const GroupPlace* places = reinterpret_cast<const GroupPlace*>(groups) + static_cast<long long>(batch) * S;
+    for (int u = threadIdx.x; u < total; u += kBuildBlock) {
+        const int bin = bin_of[u];
+        const int lo = bin_start[bin], hi = bin_cursor[bin];
+        const unsigned int mine = keys[u];
+        int rank = 0;
+        unsigned int pred = 0;
+        bool has_pred = false;
+        for (int v = lo; v < hi; ++v) {
+            const unsigned int k = keys[v];
+            if (before(v, k, u, mine)) {
+                ++rank;
+                pred = has_pred ? max(pred, k) : k;
+                has_pred = true;
+            }
+        }
+        const int lrow = static_cast<int>(mine >> 16);
+        if (PASS == 0) {
+            // markers in front of the bin's first slot depend on the cell's earlier batches: cell_place_kernel adds them
+            if (has_pred) {
+                const int need = (lrow - static_cast<int>(pred >> 16)) / kSkip;
+                if (need) atomicAdd(&bin_escapes[bin], need);
+            } else {
+                atomicOr(&bin_ends[bin], lrow << 16);                    // exactly one slot per bin has no predecessor
+            }
+            if (rank == hi - lo - 1) atomicOr(&bin_ends[bin], lrow);     // ... and exactly one is the last
+        } else {
+            const int from = has_pred ? static_cast<int>(pred >> 16) : places[bin].prev_last;   // 0: the cell starts here
+            const int gap = lrow - from;
+            const int need = gap / kSkip;                                // skip markers in front of this slot
+            rank_of[u] = static_cast<unsigned short>(rank);
+            need_delta[u] = static_cast<unsigned short>((need << 8) | (gap - need * kSkip));
+            if (need) atomicAdd(&bin_escapes[bin], need);
+        }
+    }
+    __syncthreads();
+
+    if (PASS == 0) {
+        GroupCount* out = reinterpret_cast<GroupCount*>(groups) + static_cast<long long>(batch) * S;
+        for (int i = threadIdx.x; i < S; i += kBuildBlock) {
+            GroupCount g;
+            g.count = static_cast<unsigned short>(bin_cursor[i] - bin_start[i]);
+            g.first = static_cast<unsigned short>(static_cast<unsigned int>(bin_ends[i]) >> 16);
+            g.last = static_cast<unsigned short>(bin_ends[i] & 0xFFFF);
+            g.escapes = static_cast<unsigned short>(bin_escapes[i]);
+            uint2 packed;
+            __builtin_memcpy(&packed, &g, sizeof(g));
+            groups[static_cast<long long>(batch) * S + i] = packed;
+        }
+        (void)out;
         return;
     }
-    for (int i = threadIdx.x; i < num_strips; i += kBlock) {
-        const long long cell = static_cast<long long>(i) * num_tiles + tile;
-        cursor[i] = hist[i] ? offs[cell] + atomicAdd(&cell_counter[cell], hist[i]) : 0;
-    }
-    __syncthreads();
-    for (long long row = row0 + threadIdx.x / LANES; row < row1; row += kRowsPerSweep) {
-        const int begin = row_ptrs[row], end = row_ptrs[row + 1];
-        if (end - begin > long_row) continue;
-        const unsigned short lrow = static_cast<unsigned short>(row - tile_first);
-        for (int j = begin + lane; j < end; j += LANES) {
-            const int c = cols[j];
-            const int strip = c / strip_cols;
-            const int at = atomicAdd(&cursor[strip], 1);
-            if (a_val) a_val[at] = vals[j];
-            a_lcol[at] = static_cast<unsigned short>(c - strip * strip_cols);
-            a_lrow[at] = lrow;
+
+    // ---- PASS 1 write-out: slot position = cell begin + group offset + rank + markers in front of it
+    for (int u = threadIdx.x; u < total; u += kBuildBlock) {
+        const int bin = bin_of[u];
+        const unsigned int mine = keys[u];
+        const int rank = rank_of[u];
+        const int need = need_delta[u] >> 8;
+        int markers_before = 0;
+        if (bin_escapes[bin] != 0) {                 // rare: some slot of this bin needs markers
+            for (int v = bin_start[bin]; v < bin_cursor[bin]; ++v) {
+                if (before(v, keys[v], u, mine)) markers_before += need_delta[v] >> 8;
+            }
         }
+        const long long cell = static_cast<long long>(bin) * sh.num_tiles + tile;
+        const long long at = static_cast<long long>(offs[cell]) + places[bin].rel + rank + markers_before;
+        for (int k = 0; k < need; ++k) {
+            if (a_val) a_val[at + k] = 0.0f;
+            a_lcol[at + k] = 0;
+            a_drow[at + k] = kSkip;
+        }
+        if (a_val) a_val[at + need] = vals[u];
+        a_lcol[at + need] = static_cast<unsigned short>(mine & 0xFFFF);
+        a_drow[at + need] = static_cast<unsigned char>(need_delta[u] & 0xFF);
     }
 }
 
-// ELL source: one thread per row walks the K column-major slabs (padding: col < 0).
-template <int PASS>
+// One thread per cell (tile, strip): walks the tile's batches in row order, places every group inside the
+// cell (markers between groups included) and records the cell's slot count.
 __global__ __launch_bounds__(kBlock)
-void bucket_ell_kernel(int num_rows, int width, int num_tiles, int strip_cols, int tile_rows,
-                       const int* __restrict__ cols, const float* __restrict__ vals,
-                       int* __restrict__ cell_counter, const int* __restrict__ offs,
-                       float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
-                       unsigned short* __restrict__ a_lrow) {
-    const long long row = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x;
-    if (row >= num_rows) return;
-    const int tile = static_cast<int>(row / tile_rows);
-    const unsigned short lrow = static_cast<unsigned short>(row % tile_rows);
-    for (int k = 0; k < width; ++k) {
-        const long long slot = static_cast<long long>(k) * num_rows + row;
-        const int c = cols[slot];
-        if (c < 0) continue;
-        const int strip = c / strip_cols;
-        const long long cell = static_cast<long long>(strip) * num_tiles + tile;
-        if (PASS == 0) {
-            atomicAdd(&cell_counter[cell], 1);
-        } else {
-            const int at = offs[cell] + atomicAdd(&cell_counter[cell], 1);
-            if (a_val) a_val[at] = vals[slot];
-            a_lcol[at] = static_cast<unsigned short>(c - strip * strip_cols);
-            a_lrow[at] = lrow;
+void cell_place_kernel(int num_tiles, int num_strips, const int* __restrict__ tile_batch,
+                       uint2* __restrict__ groups, int* __restrict__ cell_slots /*strip-major*/,
+                       unsigned long long* __restrict__ entry_total) {
+    const long long id = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x;
+    unsigned long long mine = 0;
+    if (id < static_cast<long long>(num_tiles) * num_strips) {
+        const int tile = static_cast<int>(id / num_strips), strip = static_cast<int>(id % num_strips);
+        int last = 0;
+        unsigned int total = 0;
+        for (int b = tile_batch[tile]; b < tile_batch[tile + 1]; ++b) {
+            uint2* slot = groups + static_cast<long long>(b) * num_strips + strip;
+            const uint2 raw = *slot;
+            GroupCount g;
+            __builtin_memcpy(&g, &raw, sizeof(g));
+            GroupPlace p;
+            p.rel = total;
+            p.prev_last = static_cast<unsigned short>(last);
+            p.unused = 0;
+            if (g.count) {
+                total += g.count + g.escapes + (g.first - last) / kSkip;
+                last = g.last;
+                mine += g.count;
+            }
+            uint2 packed;
+            __builtin_memcpy(&packed, &p, sizeof(p));
+            *slot = packed;
         }
+        cell_slots[static_cast<long long>(strip) * num_tiles + tile] = static_cast<int>(total);
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(entry_total, mine);
+}
+
+// exclusive scan of round_up_4(in[i]) in three launches: block sums, scan of the sums, block scans
+constexpr int kScanBlock = 1024, kScanPerThread = 4, kScanTile = kScanBlock * kScanPerThread;
+__device__ __forceinline__ int padded4(int v) { return (v + 3) & ~3; }
+
+__global__ __launch_bounds__(kScanBlock)
+void scan_sums_kernel(const int* __restrict__ in, long long n, long long* __restrict__ block_sum) {
+    __shared__ long long s_wave[kScanBlock / 64];
+    const long long first = static_cast<long long>(blockIdx.x) * kScanTile + threadIdx.x * kScanPerThread;
+    long long sum = 0;
+    for (int k = 0; k < kScanPerThread; ++k) if (first + k < n) sum += padded4(in[first + k]);
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long total = 0;
+        for (int w = 0; w < kScanBlock / 64; ++w) total += s_wave[w];
+        block_sum[blockIdx.x] = total;
     }
 }
 
-// out[i] = sum of in[0..i), out[n] = total.  One workgroup of 1024; each thread owns a
-// contiguous chunk (one-time cost, n <= 2^26).
-__global__ __launch_bounds__(1024)
-void exclusive_scan_kernel(const int* __restrict__ in, long long n, int* __restrict__ out) {
-    __shared__ long long s_part[1024];
-    const long long chunk = (n + 1023) / 1024;
-    const long long lo = min(n, chunk * threadIdx.x);
-    const long long hi = min(n, lo + chunk);
+__global__ __launch_bounds__(kScanBlock)
+void scan_top_kernel(long long* __restrict__ block_sum, int blocks, long long* __restrict__ grand_total) {
+    __shared__ long long s_part[kScanBlock];
+    const int per = (blocks + kScanBlock - 1) / kScanBlock;
+    const int lo = min(blocks, per * static_cast<int>(threadIdx.x)), hi = min(blocks, lo + per);
     long long sum = 0;
-    for (long long i = lo; i < hi; ++i) sum += in[i];
+    for (int i = lo; i < hi; ++i) sum += block_sum[i];
     s_part[threadIdx.x] = sum;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele over the partials
-        const long long add = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
+    for (int off = 1; off < kScanBlock; off <<= 1) {
+        const long long add = static_cast<int>(threadIdx.x) >= off ? s_part[threadIdx.x - off] : 0;
         __syncthreads();
         s_part[threadIdx.x] += add;
         __syncthreads();
     }
     long long run = threadIdx.x ? s_part[threadIdx.x - 1] : 0;
-    for (long long i = lo; i < hi; ++i) {
-        out[i] = static_cast<int>(run);
-        run += in[i];
+    for (int i = lo; i < hi; ++i) {
+        const long long v = block_sum[i];
+        block_sum[i] = run;
+        run += v;
     }
-    if (threadIdx.x == 1023) out[n] = static_cast<int>(s_part[1023]);
+    if (threadIdx.x == kScanBlock - 1) *grand_total = s_part[kScanBlock - 1];
+}
+
+__global__ __launch_bounds__(kScanBlock)
+void scan_apply_kernel(const int* __restrict__ in, long long n, const long long* __restrict__ block_sum,
+                       int* __restrict__ out /*[n + 1]*/) {
+    __shared__ int s_part[kScanBlock];
+    const long long first = static_cast<long long>(blockIdx.x) * kScanTile + threadIdx.x * kScanPerThread;
+    int v[kScanPerThread], sum = 0;
+    for (int k = 0; k < kScanPerThread; ++k) {
+        v[k] = first + k < n ? padded4(in[first + k]) : 0;
+        sum += v[k];
+    }
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {
+        const int add = static_cast<int>(threadIdx.x) >= off ? s_part[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    long long run = block_sum[blockIdx.x] + (threadIdx.x ? s_part[threadIdx.x - 1] : 0);
+    for (int k = 0; k < kScanPerThread; ++k) {
+        if (first + k < n) out[first + k] = static_cast<int>(run);
+        run += v[k];
+        if (first + k == n - 1) out[n] = static_cast<int>(run);
+    }
+}
+
+// counts[0 .. n) -> exclusive prefix sums in place, counts[n] = total.  One workgroup, each thread a contiguous piece.
+__global__ __launch_bounds__(kScanBlock)
+void exclusive_scan_small_kernel(int* __restrict__ counts, int n) {
+    __shared__ long long s_part[kScanBlock];
+    const int per = (n + kScanBlock - 1) / kScanBlock;
+    const int lo = min(n, per * static_cast<int>(threadIdx.x)), hi = min(n, lo + per);
+    long long sum = 0;
+    for (int i = lo; i < hi; ++i) sum += counts[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {
+        const long long add = static_cast<int>(threadIdx.x) >= off ? s_part[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    long long run = threadIdx.x ? s_part[threadIdx.x - 1] : 0;
+    for (int i = lo; i < hi; ++i) {
+        const int v = counts[i];
+        counts[i] = static_cast<int>(run);
+        run += v;
+    }
+    if (threadIdx.x == kScanBlock - 1) counts[n] = static_cast<int>(s_part[kScanBlock - 1]);
+}
+
+// the padding slots at the end of every cell (and nothing else): skip markers
+__global__ __launch_bounds__(kBlock)
+void cell_padding_kernel(const int* __restrict__ cell_slots, const int* __restrict__ offs, long long cells,
+                         float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
+                         unsigned char* __restrict__ a_drow) {
+    for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < cells;
+         i += static_cast<long long>(gridDim.x) * kBlock) {
+        const int used = cell_slots[i];
+        for (int k = used; k < padded4(used); ++k) {
+            const long long at = static_cast<long long>(offs[i]) + k;
+            if (a_val) a_val[at] = 0.0f;
+            a_lcol[at] = 0;
+            a_drow[at] = kSkip;
+        }
+    }
 }
 
 // Column-weight folding: when every stored entry of a column carries the same value
 // (adjacency matrices, the column-stochastic matrices of PageRank: a_ij = 1 / outdeg(j)),
 // a_ij * x_j = (w_j * x_j) is one product per column instead of one per entry, and phase 1 no
-// longer needs the value stream.  PASS 0 records a value per column, PASS 1 compares every entry
-// with it bit for bit; the plan folds only if none differs.  Padding (col < 0) is skipped.
+// longer needs the value stream.  One workgroup per strip, the strip's weights in LDS: first every
+// entry stores its value at its column, then every entry compares its bits with what stayed there.
+// Skip markers / padding (row delta 255) carry no value.  Columns without an entry in the cells keep the
+// kNoWeight bit pattern until the long rows have had their say (weight_finish_kernel turns what is left into 0).
+constexpr unsigned int kNoWeight = 0x7FC0BEEFu;       // a NaN payload no arithmetic produces
+template <int W>
+__global__ __launch_bounds__(1024)
+void strip_weight_kernel(int first_strip, const int* __restrict__ strip_begin, int num_cols,
+                         const float* __restrict__ a_val, const unsigned short* __restrict__ a_lcol,
+                         const unsigned char* __restrict__ a_drow,
+                         float* __restrict__ weight, int* __restrict__ differs) {
+    __shared__ float ws[W];
+    const int strip = first_strip + blockIdx.x;
+    const int begin = strip_begin[strip], end = strip_begin[strip + 1];
+    for (int i = threadIdx.x; i < W; i += 1024) ws[i] = __uint_as_float(kNoWeight);
+    __syncthreads();
+    for (int q = begin + threadIdx.x; q < end; q += 1024) {
+        if (a_drow[q] != kSkip) ws[a_lcol[q]] = a_val[q];
+    }
+    __syncthreads();
+    bool bad = false;
+    for (int q = begin + threadIdx.x; q < end; q += 1024) {
+        if (a_drow[q] != kSkip) bad |= __float_as_uint(ws[a_lcol[q]]) != __float_as_uint(a_val[q]);
+    }
+    if (bad) *differs = 1;
+    const long long base = static_cast<long long>(strip) * W;
+    for (int i = threadIdx.x; i < W && base + i < num_cols; i += 1024) weight[base + i] = ws[i];
+}
+
+// the long rows' entries are not in the cells: PASS 0 gives columns that only they touch a weight,
+// PASS 1 checks that every long-row entry carries its column's weight
 template <int PASS>
 __global__ __launch_bounds__(kBlock)
-void column_weight_probe_kernel(const int* __restrict__ cols, const float* __restrict__ vals, long long count,
-                                float* __restrict__ weight, int* __restrict__ differs) {
+void long_row_weight_kernel(const int* __restrict__ chunks, int num_chunks, const int* __restrict__ cols,
+                            const float* __restrict__ vals, float* __restrict__ weight,
+                            int* __restrict__ differs) {
+    const int which = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (which >= num_chunks) return;
     bool bad = false;
-    for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < count;
-         i += static_cast<long long>(gridDim.x) * kBlock) {
-        const int c = cols[i];
-        if (c < 0) continue;
+    for (int j = chunks[3 * which + 1] + (threadIdx.x & 63); j < chunks[3 * which + 2]; j += 64) {
+        unsigned int* slot = reinterpret_cast<unsigned int*>(weight + cols[j]);
         if (PASS == 0) {
-            weight[c] = vals[i];
+            if (*slot == kNoWeight) atomicCAS(slot, kNoWeight, __float_as_uint(vals[j]));
         } else {
-            bad |= __float_as_uint(weight[c]) != __float_as_uint(vals[i]);
+            bad |= *slot != __float_as_uint(vals[j]);
         }
     }
     if (PASS == 1 && bad) *differs = 1;
+}
+
+__global__ __launch_bounds__(kBlock)
+void weight_finish_kernel(float* __restrict__ weight, int n) {
+    for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+         i += static_cast<long long>(gridDim.x) * kBlock) {
+        if (__float_as_uint(weight[i]) == kNoWeight) weight[i] = 0.0f;
+    }
 }
 
 // cells_t[tile * num_strips + strip] = (begin, length) of the cell's run;
@@ -268,21 +635,6 @@ void cell_table_kernel(const int* __restrict__ offs, int num_strips, int num_til
         if (i <= num_strips) strip_begin[i] = offs[i * num_tiles];
     }
 }
-
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each XCD has its
-// own L2).  Both phases hand every XCD a CONTIGUOUS range of the work list, walked in order:
-// neighbours in the list then run on one XCD at about the same time and share what they both
-// touch through its L2 — the x strip of consecutive phase-1 items, the 128-byte lines that
-// adjacent runs of neighbouring tiles straddle in phase 2.  Returns -1 for the padding blocks of a
-// grid rounded up to a multiple of 8.  (Speed only: correctness never depends on placement.
-// Measured against the plain order on one box: C2 59.1 -> 55.0 us, C5 535.5 -> 530.1 us, 1/8 shard 84.5 -> 85.2 us.)
-constexpr int kXcds = 8;
-__device__ __forceinline__ int xcd_contiguous(int block, int count) {
-    const int per_xcd = (count + kXcds - 1) / kXcds;
-    const int which = (block % kXcds) * per_xcd + block / kXcds;
-    return block / kXcds < per_xcd && which < count ? which : -1;
-}
-__host__ inline int xcd_grid(int count) { return (count + kXcds - 1) / kXcds * kXcds; }
 
 // ------------------------------------------------------------------------ phase 1 ----
 // Rows too long for the cells are cut into chunks of kLongChunk entries; one wavefront per
@@ -422,14 +774,32 @@ __device__ __forceinline__ void lds_add(float* slot, float v) {
     }
 }
 
+// inclusive prefix sum over the 64 lanes of a wavefront: Hillis-Steele inside each 16-lane DPP row
+// (row_shr 1, 2, 4, 8; lanes shifted in from outside the row contribute 0), then the classic wave64 tail:
+// row_bcast:15 adds lane 15 of the previous row into rows 1 and 3, row_bcast:31 adds lane 31 into rows 2, 3
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
 // Fills the LDS tile with the sums of this tile's rows.  `seed` (may be null) holds the
-// long rows' sums and zeros elsewhere.
-template <int kReduceBlock, int U>
-__device__ __forceinline__ void tile_accumulate(float* tile, int R, int tile_index, int num_strips, int num_rows,
+// long rows' sums and zeros elsewhere.  The tile accumulates in DOUBLE: every fp32 product is added
+// exactly as often as fp64 allows (products of one row rarely span more than 29 binades), so the row
+// sums no longer depend on the order in which the wavefronts' adds meet, and they are rounded to
+// fp32 once, on the way out.
+// E = slots per lane per load (4: 16-byte product + 4-byte delta loads; 2 for matrices with short runs).
+template <int kReduceBlock, int E, int kRuns>
+__device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_index, int num_strips, int num_rows,
                                                 const int2* __restrict__ cells_t,
                                                 const float* __restrict__ prod,
-                                                const unsigned short* __restrict__ a_lrow,
+                                                const unsigned char* __restrict__ a_drow,
                                                 float* __restrict__ seed) {
+    __shared__ double spare[64];           // where a lane's slots without an entry "add" (never read)
     const long long first = static_cast<long long>(tile_index) * R;
     for (int i = threadIdx.x; i < R; i += kReduceBlock) {
         float v = 0.0f;
@@ -437,120 +807,158 @@ __device__ __forceinline__ void tile_accumulate(float* tile, int R, int tile_ind
             v = seed[first + i];
             if (v != 0.0f) seed[first + i] = 0.0f;      // leave the seed vector clean for the next call
         }
-        tile[i] = v;
+        tile[i] = static_cast<double>(v);
     }
     __syncthreads();
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    typedef float prod_t __attribute__((ext_vector_type(E)));
+    typedef unsigned int delta_word_t;
+    // (phase 2 is bound by vector-instruction issue once its loads are wide: rocprofv3 counted ~160 VALU
+    // instructions per 128-slot run chunk in a first version, 85 % of the kernel's cycles.  Hence: run
+    // geometry kept in scalar registers (v_readlane, not ds_bpermute), addresses as scalar base + one shared
+    // 32-bit lane offset, no per-run branches around the loads (out-of-run lanes re-read the run's last
+    // group and are masked afterwards), two pass records used alternately instead of copied.)
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const unsigned int lane = threadIdx.x & 63;
     constexpr int kWaves = kReduceBlock / 64;
-    // A group of kRuns runs is processed together, U chunks of 64 entries from each per pass:
-    // all 8 loads of a pass are issued before its first add, and a pass is repeated only while
-    // some run of the group still has entries left (U is picked from the mean run length).
-    constexpr int kSlots = 8;             // (run, chunk) loads in flight per lane (16 measured slower)
-    constexpr int kRuns = kSlots / U;
+    static_assert(64 % kRuns == 0, "a group of runs never straddles two 64-run windows of the cell table");
+    // Every wavefront owns a contiguous share of the tile's runs (one run per strip) and walks it in groups
+    // of kRuns runs, one chunk of 64 * E slots from each run per PASS.  Passes are software-pipelined: the
+    // loads of pass n + 1 (16- or 8-byte products, 4- or 2-byte deltas) are issued before pass n's products
+    // go into the LDS tile.  A run's rows are rebuilt from its deltas: in-lane prefix over the lane's E
+    // slots, one wavefront scan over the lanes' totals, plus the row the run's previous chunk ended at.
+    const int per_wave = (num_strips + kWaves - 1) / kWaves;
+    const int run_lo = min(num_strips, wave * per_wave), run_hi = min(num_strips, run_lo + per_wave);
     const int2* mine = cells_t + static_cast<long long>(tile_index) * num_strips;
-    int2 meta_next = lane < num_strips ? mine[lane] : make_int2(0, 0);
-    for (int s0 = 0; s0 < num_strips; s0 += 64) {
-        // the tile's next 64 runs: every wavefront loads their (begin, length) (one coalesced
-        // 512-byte load, L1-shared; fetched one batch ahead so its latency hides behind the
-        // current batch) and takes every kWaves-th group of kRuns runs
-        const int2 meta = meta_next;
-        meta_next = s0 + 64 + lane < num_strips ? mine[s0 + 64 + lane] : make_int2(0, 0);
-        const int runs = min(64, num_strips - s0);
-        for (int k0 = wave * kRuns; k0 < runs; k0 += kWaves * kRuns) {
-            int begin[kRuns], len[kRuns], lead[kRuns];
-            int longest = 0;
+    // window of 64 (begin, length) records, lane l holds run window_first + l; the next window is fetched early
+    int window_first = run_lo;
+    int2 window = run_lo + static_cast<int>(lane) < run_hi ? mine[run_lo + lane] : make_int2(0, 0);
+    int2 window_ahead = run_lo + 64 + static_cast<int>(lane) < run_hi ? mine[run_lo + 64 + lane] : make_int2(0, 0);
+
+    struct Pass {
+        int begin[kRuns], len[kRuns];      // wave-uniform; len: a multiple of 4 slots
+        int done, longest;                 // wave-uniform
+        bool valid;
+        prod_t p[kRuns];
+        delta_word_t d[kRuns];
+    };
+    int group = run_lo;                    // first run of the group opened next
+    auto open_group = [&](Pass& ps) {
+        ps.valid = group < run_hi;
+        ps.done = 0;
+        ps.longest = 0;
+        if (!ps.valid) return;
+        if (group >= window_first + 64) {
+            window_first += 64;
+            window = window_ahead;
+            window_ahead = window_first + 64 + static_cast<int>(lane) < run_hi ? mine[window_first + 64 + lane]
+                                                                              : make_int2(0, 0);
+        }
 #pragma unroll
-            for (int j = 0; j < kRuns; ++j) {
-                const int k = min(k0 + j, 63);
-                begin[j] = __shfl(meta.x, k, 64);
-                len[j] = k0 + j < runs ? __shfl(meta.y, k, 64) : 0;
-                longest = max(longest, len[j]);
+        for (int j = 0; j < kRuns; ++j) {
+            const int k = min(group + j - window_first, 63);
+            ps.begin[j] = __builtin_amdgcn_readlane(window.x, k);
+            ps.len[j] = group + j < run_hi ? __builtin_amdgcn_readlane(window.y, k) : 0;
+            ps.longest = max(ps.longest, ps.len[j]);
+        }
+        group += kRuns;
+    };
+    auto next_pass = [&](Pass& to, const Pass& from) {
+        to.valid = true;
+        to.done = from.done + 64 * E;
+        to.longest = from.longest;
+#pragma unroll
+        for (int j = 0; j < kRuns; ++j) {
+            to.begin[j] = from.begin[j];
+            to.len[j] = from.len[j];
+        }
+        if (to.done >= from.longest) open_group(to);
+    };
+    auto issue_loads = [&](Pass& ps) {
+        const unsigned int i = static_cast<unsigned int>(ps.done) + E * lane;
+#pragma unroll
+        for (int j = 0; j < kRuns; ++j) {
+            // lanes past the run's end re-read its last group (same cache line, no extra traffic); masked below
+            const unsigned int last = static_cast<unsigned int>(max(ps.len[j] - E, 0));
+            const unsigned int at = min(i, last);
+            const char* products = reinterpret_cast<const char*>(prod + ps.begin[j]);
+            const char* deltas = reinterpret_cast<const char*>(a_drow + ps.begin[j]);
+            ps.p[j] = *reinterpret_cast<const prod_t*>(products + static_cast<size_t>(at << 2));
+            if (E == 4) ps.d[j] = *reinterpret_cast<const unsigned int*>(deltas + static_cast<size_t>(at));
+            else        ps.d[j] = *reinterpret_cast<const unsigned short*>(deltas + static_cast<size_t>(at));
+        }
+    };
+
+    int row_base[kRuns];                   // wave-uniform: row the run's previous chunk ended at
+    auto process = [&](const Pass& ps) {
+        const unsigned int i = static_cast<unsigned int>(ps.done) + E * lane;
+#pragma unroll
+        for (int j = 0; j < kRuns; ++j) {
+            if (ps.done == 0) row_base[j] = 0;
+            if (ps.done >= ps.len[j]) continue;             // wave-uniform
+            // lanes past the run's end see skip markers only (the run ends in this chunk, so what they add to
+            // the scan is never used)
+            const unsigned int word = i < static_cast<unsigned int>(ps.len[j]) ? ps.d[j] : 0xFFFFFFFFu;
+            int delta[E], upto[E];
+            int sum = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                delta[e] = (word >> (8 * e)) & 0xFF;
+                sum += delta[e];
+                upto[e] = sum;
             }
-            if (U >= 2) {
-                // pairs of entries per lane (8-byte product / 4-byte row loads): runs re-based to an
-                // even entry, the odd leading entry masked off
+            const int incl = wave_inclusive_scan(sum);
+            const int lane_base = row_base[j] + incl - sum;
+            row_base[j] += __builtin_amdgcn_readlane(incl, 63);
+            // One LDS atomic per slot: ds_add_f64 (no return value, no retry loop, equal rows in one
+            // instruction are the hardware's business; gfx950 runs it at 3.5 lanes/clk/CU on random rows,
+            // the fp32 form at 0.38 — tools/lds_bench.hip).  Skip markers aim at a per-lane spare word, so
+            // nothing here needs an execution mask.
 #pragma unroll
-                for (int j = 0; j < kRuns; ++j) {
-                    lead[j] = begin[j] & 1;
-                    len[j] += lead[j];
-                    begin[j] &= ~1;
-                }
-                longest += 1;
-            }
-            for (int done = 0; done < longest; done += 64 * U) {
-                float p[kSlots];
-                int r[kSlots];
-                if (U >= 2) {
-#pragma unroll
-                    for (int j = 0; j < kRuns; ++j) {
-#pragma unroll
-                        for (int u = 0; u < U; u += 2) {
-                            const int i = done + u * 64 + 2 * lane;
-                            const bool ok = i < len[j];          // the pair is inside the allocation whenever its first entry is
-                            f32x2 pv = {0.0f, 0.0f};
-                            u16x2 rv = {0, 0};
-                            if (ok) {
-                                pv = *reinterpret_cast<const f32x2*>(prod + begin[j] + i);
-                                rv = *reinterpret_cast<const u16x2*>(a_lrow + begin[j] + i);
-                            }
-                            const bool first = ok && i >= lead[j];
-                            p[j * U + u] = pv[0];
-                            r[j * U + u] = first ? rv[0] : -1;
-                            p[j * U + u + 1] = pv[1];
-                            r[j * U + u + 1] = (ok && i + 1 < len[j]) ? rv[1] : -1;
-                            // two neighbouring entries of one row (the build places a row's entries of a
-                            // cell side by side): one LDS add instead of two colliding ones
-                            if (r[j * U + u] >= 0 && r[j * U + u] == r[j * U + u + 1]) {
-                                p[j * U + u] = __fadd_rn(p[j * U + u], p[j * U + u + 1]);
-                                r[j * U + u + 1] = -1;
-                            }
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < kRuns; ++j) {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const int i = done + u * 64 + lane;
-                            const bool ok = i < len[j];
-                            p[j * U + u] = ok ? prod[begin[j] + i] : 0.0f;
-                            r[j * U + u] = ok ? a_lrow[begin[j] + i] : -1;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < kSlots; ++q) {
-                    if (r[q] >= 0) lds_add(&tile[r[q]], p[q]);
-                }
+            for (int e = 0; e < E; ++e) {
+                double* target = delta[e] != kSkip ? &tile[lane_base + upto[e]] : &spare[lane];
+                atomicAdd(target, static_cast<double>(ps.p[j][e]));
             }
         }
+    };
+
+    Pass a, b;
+    open_group(a);
+    if (a.valid) issue_loads(a);
+    while (a.valid) {
+        next_pass(b, a);
+        if (b.valid) issue_loads(b);
+        process(a);
+        if (!b.valid) break;
+        next_pass(a, b);
+        if (a.valid) issue_loads(a);
+        process(b);
     }
     __syncthreads();
 }
 
-// The tile (R floats, R = plan.tile_rows: any multiple of 64) lives in dynamic LDS.
-template <int kReduceBlock, int U>
-__global__ __launch_bounds__(kReduceBlock)
+// The tile (R doubles, R = plan.tile_rows: any multiple of 64) lives in dynamic LDS.
+template <int kReduceBlock, int E, int kRuns>
+__global__ __launch_bounds__(kReduceBlock, kReduceBlock / 128)     // two tiles per CU: 8 (1024 threads) or 4 wavefronts per SIMD
 void tiled_reduce_kernel(int R, int num_tiles, const int2* __restrict__ cells_t, int num_strips,
                          const float* __restrict__ prod,
-                         const unsigned short* __restrict__ a_lrow,
+                         const unsigned char* __restrict__ a_drow,
                          float* __restrict__ seed,
                          int num_rows, float* __restrict__ y) {
-    extern __shared__ float tile[];
+    extern __shared__ double tile[];
     const int tile_index = xcd_contiguous(blockIdx.x, num_tiles);
     if (tile_index < 0) return;
-    tile_accumulate<kReduceBlock, U>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_lrow, seed);
+    tile_accumulate<kReduceBlock, E, kRuns>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_drow, seed);
     const long long first = static_cast<long long>(tile_index) * R;
-    for (int i = threadIdx.x; i < R && first + i < num_rows; i += kReduceBlock) y[first + i] = tile[i];
+    for (int i = threadIdx.x; i < R && first + i < num_rows; i += kReduceBlock) y[first + i] = static_cast<float>(tile[i]);
 }
 
 // phase 2 with the PageRank update fused into the tile write-out (cf. pr_step_kernel)
-template <int kReduceBlock, int U>
-__global__ __launch_bounds__(kReduceBlock)
+template <int kReduceBlock, int E, int kRuns>
+__global__ __launch_bounds__(kReduceBlock, kReduceBlock / 128)
 void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__ cells_t, int num_strips,
                                   const float* __restrict__ prod,
-                                  const unsigned short* __restrict__ a_lrow,
+                                  const unsigned char* __restrict__ a_drow,
                                   float* __restrict__ seed,
                                   int local_rows, int row_offset, int n_global,
                                   const float* __restrict__ r_old, float* __restrict__ r_new,
@@ -558,10 +966,10 @@ void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__
                                   const PrState* __restrict__ state,
                                   double* __restrict__ block_partials, PushTargets push) {
     if (state->done) return;
-    extern __shared__ float tile[];
+    extern __shared__ double tile[];
     const int tile_index = xcd_contiguous(blockIdx.x, num_tiles);
     if (tile_index < 0) return;
-    tile_accumulate<kReduceBlock, U>(tile, R, tile_index, num_strips, local_rows, cells_t, prod, a_lrow, seed);
+    tile_accumulate<kReduceBlock, E, kRuns>(tile, R, tile_index, num_strips, local_rows, cells_t, prod, a_drow, seed);
 
     const float teleport = __fdiv_rn(1.0f - damping, static_cast<float>(n_global));
     const float dangling_term = __fdiv_rn(__fmul_rn(damping, state->dangling_sum),
@@ -570,7 +978,7 @@ void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__
     const long long first = static_cast<long long>(tile_index) * R;
     for (int i = threadIdx.x; i < R && first + i < local_rows; i += kReduceBlock) {
         const long long node = row_offset + first + i;
-        const float fresh = __fadd_rn(__fadd_rn(__fmul_rn(damping, tile[i]), dangling_term), teleport);
+        const float fresh = __fadd_rn(__fadd_rn(__fmul_rn(damping, static_cast<float>(tile[i])), dangling_term), teleport);
         r_new[node] = fresh;
         for (int p = 0; p < push.count; ++p) push.ptr[p][node] = fresh;     // straight into the peers' vectors
         const float diff = __fsub_rn(fresh, r_old[node]);
@@ -587,52 +995,6 @@ void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__
 template <typename T>
 hipError_t dev_alloc(T** p, long long count) {
     return hipMalloc(reinterpret_cast<void**>(p), static_cast<size_t>(std::max<long long>(count, 1)) * sizeof(T));
-}
-
-constexpr int kBucketLdsMaxStrips = 7680;     // 2 x 4 B x strips of dynamic LDS stays under the 64 KiB default limit
-
-template <int LANES, int PASS>
-hipError_t launch_bucket(const CSRMatrix* A, const TiledPlan& plan, int* counter, const int* offs,
-                         int* num_long, hipStream_t s) {
-    if (plan.num_strips <= kBucketLdsMaxStrips) {
-        // ~16 K entries per workgroup, whole sweeps of rows, never across a tile boundary
-        constexpr int kRowsPerSweep = kBlock / LANES;
-        const double mean = std::max(1.0, static_cast<double>(A->nnz) / std::max(A->num_rows, 1));
-        long long rows_per_block = static_cast<long long>(16384.0 / mean);
-        rows_per_block = std::max<long long>(kRowsPerSweep, rows_per_block / kRowsPerSweep * kRowsPerSweep);
-        rows_per_block = std::min<long long>(rows_per_block, (plan.tile_rows + kRowsPerSweep - 1) / kRowsPerSweep * kRowsPerSweep);
-        const int blocks_per_tile = static_cast<int>((plan.tile_rows + rows_per_block - 1) / rows_per_block);
-        const long long grid = static_cast<long long>(plan.num_tiles) * blocks_per_tile;
-        if (grid <= 0x7fffffffLL) {
-            const size_t lds = static_cast<size_t>(plan.num_strips) * sizeof(int) * (PASS == 0 ? 1 : 2);
-            bucket_lds_kernel<LANES, PASS><<<static_cast<int>(grid), kBlock, lds, s>>>(
-                A->num_rows, plan.num_tiles, plan.num_strips, plan.strip_cols, plan.tile_rows, plan.long_row,
-                static_cast<int>(rows_per_block), blocks_per_tile, A->d_row_ptrs, A->d_col_indices, A->d_values,
-                counter, offs, plan.a_val, plan.a_lcol, plan.a_lrow, plan.long_rows, num_long);
-            return hipGetLastError();
-        }
-    }
-    const int rows_per_block = kBlock / LANES;
-    const int grid = (A->num_rows + rows_per_block - 1) / rows_per_block;
-    bucket_kernel<LANES, PASS><<<grid, kBlock, 0, s>>>(
-        A->num_rows, plan.num_tiles, plan.strip_cols, plan.tile_rows, plan.long_row, A->d_row_ptrs,
-        A->d_col_indices, A->d_values,
-        counter, offs, plan.a_val, plan.a_lcol, plan.a_lrow, plan.long_rows, num_long);
-    return hipGetLastError();
-}
-
-template <int PASS>
-hipError_t launch_bucket_lanes(int lanes, const CSRMatrix* A, const TiledPlan& plan, int* counter,
-                               const int* offs, int* num_long, hipStream_t s) {
-    switch (lanes) {
-        case 1:  return launch_bucket<1, PASS>(A, plan, counter, offs, num_long, s);
-        case 2:  return launch_bucket<2, PASS>(A, plan, counter, offs, num_long, s);
-        case 4:  return launch_bucket<4, PASS>(A, plan, counter, offs, num_long, s);
-        case 8:  return launch_bucket<8, PASS>(A, plan, counter, offs, num_long, s);
-        case 16: return launch_bucket<16, PASS>(A, plan, counter, offs, num_long, s);
-        case 32: return launch_bucket<32, PASS>(A, plan, counter, offs, num_long, s);
-        default: return launch_bucket<64, PASS>(A, plan, counter, offs, num_long, s);
-    }
 }
 
 // W / R for a matrix: as many row tiles as it takes to fill the chip several times over
@@ -707,29 +1069,45 @@ hipError_t launch_expand(const TiledPlan& plan, const float* d_x, const PrState*
     }
 }
 
-template <int U>
+// threads per phase-2 workgroup (two workgroups per CU either way): 1024 = 32 wavefronts per CU
+int reduce_block() {
+    static const int block = [] {
+        const char* env = std::getenv("SPMV_TILED_REDUCE_BLOCK");
+        return env && std::atoi(env) == 512 ? 512 : 1024;
+    }();
+    return block;
+}
+
+template <int BLOCK, int E, int kRuns>
 hipError_t launch_reduce_as(const TiledPlan& plan, float* d_y, hipStream_t s) {
-    tiled_reduce_kernel<512, U><<<xcd_grid(plan.num_tiles), 512, plan.tile_rows * sizeof(float), s>>>(
-        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_lrow,
+    const size_t lds = static_cast<size_t>(plan.tile_rows) * sizeof(double);
+    const void* kernel = reinterpret_cast<const void*>(&tiled_reduce_kernel<BLOCK, E, kRuns>);
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    tiled_reduce_kernel<BLOCK, E, kRuns><<<xcd_grid(plan.num_tiles), BLOCK, lds, s>>>(
+        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_drow,
         plan.seed, plan.num_rows, d_y);
     return hipGetLastError();
 }
 
 hipError_t launch_reduce(const TiledPlan& plan, float* d_y, hipStream_t s) {
-    switch (plan.run_chunks) {
-        case 1:  return launch_reduce_as<1>(plan, d_y, s);
-        case 2:  return launch_reduce_as<2>(plan, d_y, s);
-        default: return launch_reduce_as<4>(plan, d_y, s);
+    if (reduce_block() == 512) {
+        return plan.lane_entries == 2 ? launch_reduce_as<512, 2, 4>(plan, d_y, s) : launch_reduce_as<512, 4, 4>(plan, d_y, s);
     }
+    return plan.lane_entries == 2 ? launch_reduce_as<1024, 2, 4>(plan, d_y, s) : launch_reduce_as<1024, 4, 2>(plan, d_y, s);
 }
 
-template <int U>
+template <int BLOCK, int E, int kRuns>
 hipError_t launch_pagerank_reduce_as(const TiledPlan& plan, int row_offset, int n_global, const float* d_r_old,
                                      float* d_r_new, const unsigned char* d_dangling, float damping,
                                      const PrState* d_state, double* d_block_partials,
                                      const PushTargets& push, hipStream_t s) {
-    tiled_pagerank_reduce_kernel<512, U><<<xcd_grid(plan.num_tiles), 512, plan.tile_rows * sizeof(float), s>>>(
-        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_lrow,
+    const size_t lds = static_cast<size_t>(plan.tile_rows) * sizeof(double);
+    const void* kernel = reinterpret_cast<const void*>(&tiled_pagerank_reduce_kernel<BLOCK, E, kRuns>);
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    tiled_pagerank_reduce_kernel<BLOCK, E, kRuns><<<xcd_grid(plan.num_tiles), BLOCK, lds, s>>>(
+        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_drow,
         plan.seed, plan.num_rows, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
         d_block_partials, push);
     return hipGetLastError();
@@ -739,14 +1117,12 @@ hipError_t launch_pagerank_reduce(const TiledPlan& plan, int row_offset, int n_g
                                   float* d_r_new, const unsigned char* d_dangling, float damping,
                                   const PrState* d_state, double* d_block_partials,
                                   const PushTargets& push, hipStream_t s) {
-    switch (plan.run_chunks) {
-        case 1:  return launch_pagerank_reduce_as<1>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                     damping, d_state, d_block_partials, push, s);
-        case 2:  return launch_pagerank_reduce_as<2>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                     damping, d_state, d_block_partials, push, s);
-        default: return launch_pagerank_reduce_as<4>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling,
-                                                     damping, d_state, d_block_partials, push, s);
-    }
+#define SPMV_PR_REDUCE(BLOCK, E, RUNS) \
+    launch_pagerank_reduce_as<BLOCK, E, RUNS>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state, \
+                                              d_block_partials, push, s)
+    if (reduce_block() == 512) return plan.lane_entries == 2 ? SPMV_PR_REDUCE(512, 2, 4) : SPMV_PR_REDUCE(512, 4, 4);
+    return plan.lane_entries == 2 ? SPMV_PR_REDUCE(1024, 2, 4) : SPMV_PR_REDUCE(1024, 4, 2);
+#undef SPMV_PR_REDUCE
 }
 
 } // namespace
@@ -771,7 +1147,8 @@ bool eligible_dims(long long rows, long long cols, long long nnz) {
     if (!enabled || rows <= 0 || nnz < min_nnz || cols < min_cols) return false;
     int w = 0, r = 0;
     choose_shape(rows, cols, nnz, &w, &r);
-    return ((cols + w - 1) / w) * ((rows + r - 1) / r) <= kMaxCells;
+    const long long strips = (cols + w - 1) / w;
+    return strips <= kMaxBuildStrips && strips * ((rows + r - 1) / r) <= kMaxCells;
 }
 
 // where the entries come from: exactly one of csr / ell is set
@@ -822,7 +1199,7 @@ hipError_t tiled_build(const ELLMatrix* A, TiledPlan** out, hipStream_t s) {
 
 void tiled_free(TiledPlan* p) {
     if (!p) return;
-    void* owned[] = {p->a_val, p->a_lcol, p->a_lrow, p->prod, p->cells_t, p->items, p->long_rows, p->long_chunks,
+    void* owned[] = {p->a_val, p->a_lcol, p->a_drow, p->prod, p->cells_t, p->items, p->long_rows, p->long_chunks,
                      p->seed, p->col_weight};
     for (void* q : owned) if (q) (void)hipFree(q);
     delete p;
@@ -830,7 +1207,138 @@ void tiled_free(TiledPlan* p) {
 
 namespace {
 
+// the device passes of the build for one entry source
+template <typename Src>
+hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, bool want_values,
+                       std::vector<int>* host_strip, hipStream_t s) {
+    const int S = plan->num_strips, T = plan->num_tiles;
+    const long long cells = static_cast<long long>(S) * T;
+
+    int *d_small = nullptr;            // [0] longest row, [1] long-row count
+    int *tile_batch = nullptr, *batch_row = nullptr, *batch_tile = nullptr, *cell_slots = nullptr, *offs = nullptr;
+    int *strip_begin = nullptr;
+    long long* block_sum = nullptr;    // scan scratch; [blocks] sums, then [blocks] grand total, [blocks + 1] entry count
+    uint2* groups = nullptr;
+    auto cleanup = [&](hipError_t e) {
+        for (void* q : {static_cast<void*>(d_small), static_cast<void*>(tile_batch), static_cast<void*>(batch_row),
+                        static_cast<void*>(batch_tile), static_cast<void*>(cell_slots), static_cast<void*>(offs),
+                        static_cast<void*>(strip_begin), static_cast<void*>(block_sum), static_cast<void*>(groups)}) {
+            if (q) (void)hipFree(q);
+        }
+        return e;
+    };
+    const int scan_blocks = static_cast<int>((cells + kScanTile - 1) / kScanTile);
+    const int tile_scan_blocks = (T + kScanTile - 1) / kScanTile;
+
+    hipError_t e = dev_alloc(&d_small, 2);
+    if (e == hipSuccess) e = dev_alloc(&tile_batch, static_cast<long long>(T) + 1);
+    if (e == hipSuccess) e = dev_alloc(&cell_slots, cells);
+    if (e == hipSuccess) e = dev_alloc(&offs, cells + 1);
+    if (e == hipSuccess) e = dev_alloc(&strip_begin, S + 1);
+    if (e == hipSuccess) e = dev_alloc(&block_sum, std::max(scan_blocks, tile_scan_blocks) + 2);
+    if (e == hipSuccess) e = hipMemsetAsync(d_small, 0, 2 * sizeof(int), s);
+    if (e != hipSuccess) return cleanup(e);
+
+    // ---- batch geometry: how many entries a builder workgroup can hold in LDS
+    const int lds_bytes = S <= 1024 ? kBuildLdsSmall : kBuildLdsLarge;
+    int capacity = (lds_bytes - kBuildBinWords * 4 * S) / kBuildEntryBytes / 64 * 64;
+    if (capacity < 512) return cleanup(hipErrorInvalidValue);
+    capacity = std::min(capacity, 65535 / 2);        // group counts are 16-bit
+    max_row_kernel<<<std::min(2048, (plan->num_rows + kBlock - 1) / kBlock), kBlock, 0, s>>>(dev_src, plan->num_rows, d_small);
+    int longest = 0;
+    e = hipMemcpyAsync(&longest, d_small, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return cleanup(e);
+    const int longest_short = std::min(longest, plan->long_row);
+    if (longest_short >= capacity) plan->long_row = capacity / 2;      // (rows that long go the direct way)
+    BuildShape sh;
+    sh.num_rows = plan->num_rows;
+    sh.num_tiles = T;
+    sh.num_strips = S;
+    sh.strip_shift = __builtin_ctz(static_cast<unsigned>(plan->strip_cols));
+    sh.tile_rows = plan->tile_rows;
+    sh.long_row = plan->long_row;
+    sh.quota = std::max(64, capacity - std::min(longest, plan->long_row));
+    sh.any_long = longest > plan->long_row ? 1 : 0;
+
+    tile_batches_kernel<<<(T + kBlock - 1) / kBlock, kBlock, 0, s>>>(dev_src, sh, tile_batch);
+    // exclusive scan of the per-tile batch counts (one workgroup: T is at most a few hundred thousand)
+    exclusive_scan_small_kernel<<<1, kScanBlock, 0, s>>>(tile_batch, T);
+    int num_batches = 0;
+    e = hipMemcpyAsync(&num_batches, tile_batch + T, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return cleanup(e);
+
+    const long long group_count = static_cast<long long>(num_batches) * S;
+    e = dev_alloc(&batch_row, static_cast<long long>(num_batches) + 1);
+    if (e == hipSuccess) e = dev_alloc(&batch_tile, num_batches);
+    if (e == hipSuccess) e = dev_alloc(&groups, group_count);
+    if (e == hipSuccess && has_long_path) {
+        e = dev_alloc(&plan->long_rows, plan->csr_nnz / std::max(plan->long_row, 1) + 1);
+    }
+    if (e != hipSuccess) return cleanup(e);
+    batch_rows_kernel<<<T, kBlock, 0, s>>>(dev_src, sh, tile_batch, batch_row, batch_tile);
+
+    // ---- pass 0: group sizes; cell placement; scan
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_sort_kernel<Src, 0>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_sort_kernel<Src, 1>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return cleanup(e);
+    batch_sort_kernel<Src, 0><<<xcd_grid(num_batches), kBuildBlock, lds_bytes, s>>>(
+        dev_src, sh, num_batches, capacity, batch_row, batch_tile, groups, nullptr, nullptr, nullptr, nullptr,
+        plan->long_rows, d_small + 1);
+    unsigned long long* entry_total = reinterpret_cast<unsigned long long*>(block_sum + scan_blocks + 1);
+    e = hipMemsetAsync(entry_total, 0, sizeof(unsigned long long), s);
+    cell_place_kernel<<<static_cast<int>((cells + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, S, tile_batch, groups, cell_slots,
+                                                                                       entry_total);
+    scan_sums_kernel<<<scan_blocks, kScanBlock, 0, s>>>(cell_slots, cells, block_sum);
+    scan_top_kernel<<<1, kScanBlock, 0, s>>>(block_sum, scan_blocks, block_sum + scan_blocks);
+    scan_apply_kernel<<<scan_blocks, kScanBlock, 0, s>>>(cell_slots, cells, block_sum, offs);
+    if (e == hipSuccess) e = hipGetLastError();
+    long long totals[2] = {0, 0};          // slots, entries
+    int num_long = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(totals, block_sum + scan_blocks, 2 * sizeof(long long), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&num_long, d_small + 1, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return cleanup(e);
+    if (totals[0] >= 0x7fffffffLL - 64) return cleanup(hipErrorInvalidValue);       // slot indices are 32-bit
+    plan->nnz = totals[0];
+    plan->entries = totals[1];
+    plan->num_long = num_long;
+
+    // ---- pass 1: write the slots
+    if (want_values) e = dev_alloc(&plan->a_val, plan->nnz + 8);
+    // + 8: the 16-byte loads of a run's last group stay inside the allocation whatever its alignment
+    if (e == hipSuccess) e = dev_alloc(&plan->a_lcol, plan->nnz + 8);
+    if (e == hipSuccess) e = dev_alloc(&plan->a_drow, plan->nnz + 8);
+    if (e == hipSuccess) e = dev_alloc(&plan->cells_t, 2 * cells);
+    if (e != hipSuccess) return cleanup(e);
+    if (plan->nnz > 0) {
+        batch_sort_kernel<Src, 1><<<xcd_grid(num_batches), kBuildBlock, lds_bytes, s>>>(
+            dev_src, sh, num_batches, capacity, batch_row, batch_tile, groups, offs, plan->a_val, plan->a_lcol,
+            plan->a_drow, nullptr, nullptr);
+        cell_padding_kernel<<<static_cast<int>(std::min<long long>((cells + kBlock - 1) / kBlock, 4096)), kBlock, 0, s>>>(
+            cell_slots, offs, cells, plan->a_val, plan->a_lcol, plan->a_drow);
+    }
+    {
+        const int grid = static_cast<int>(std::min<long long>((cells + kBlock) / kBlock, 4096));
+        cell_table_kernel<<<grid, kBlock, 0, s>>>(offs, S, T, reinterpret_cast<int2*>(plan->cells_t), strip_begin);
+    }
+    e = hipGetLastError();
+    host_strip->assign(S + 1, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(host_strip->data(), strip_begin, host_strip->size() * sizeof(int),
+                                            hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return cleanup(e);
+    // strip_begin is needed again by the fold probe: hand it to the plan's scratch (freed by the caller)
+    plan->items = strip_begin;          // temporarily; build_plan replaces it
+    strip_begin = nullptr;
+    return cleanup(hipSuccess);
+}
+
 hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
+    const auto t_begin = std::chrono::steady_clock::now();
     const CSRMatrix* A = src.csr;          // null for an ELL source (then no long-row path)
     *out = nullptr;
     TiledPlan* plan = new TiledPlan();
@@ -843,7 +1351,6 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         plan->csr_vals = A->d_values;
     }
     choose_shape(src.rows, src.cols, src.nnz, &plan->strip_cols, &plan->tile_rows);
-    plan->run_chunks = 2;
     plan->num_strips = (src.cols + plan->strip_cols - 1) / plan->strip_cols;
     plan->num_tiles = (src.rows + plan->tile_rows - 1) / plan->tile_rows;
     const long long cells = static_cast<long long>(plan->num_strips) * plan->num_tiles;
@@ -857,68 +1364,38 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     if (const char* env = std::getenv("SPMV_TILED_LONG_FACTOR")) long_factor = std::max(1, std::atoi(env));
     int long_cap = kMaxLongRow;
     if (const char* env = std::getenv("SPMV_TILED_LONG_CAP")) long_cap = std::max(64, std::atoi(env));
-    plan->long_row = A ? std::max(64, std::min(long_cap, long_factor * plan->num_strips)) : 0x7fffffff;
-    const long long long_capacity = src.nnz / plan->long_row + 1;
+    plan->long_row = A ? std::max(64, std::min(long_cap, long_factor * plan->num_strips)) : 0x3fffffff;
 
-    int *cnt = nullptr, *offs = nullptr, *strip_begin = nullptr, *num_long = nullptr;
-    auto cleanup = [&](hipError_t e) {
-        for (int* q : {cnt, offs, strip_begin, num_long}) if (q) (void)hipFree(q);
-        if (e != hipSuccess) tiled_free(plan);
+    auto fail = [&](hipError_t e) {
+        tiled_free(plan);
         return e;
     };
 
-    hipError_t e = dev_alloc(&cnt, cells);
-    if (e == hipSuccess) e = dev_alloc(&offs, cells + 1);
-    if (e == hipSuccess) e = dev_alloc(&strip_begin, plan->num_strips + 1);
-    if (e == hipSuccess) e = dev_alloc(&num_long, 1);
-    if (e == hipSuccess) e = dev_alloc(&plan->long_rows, long_capacity);
-    if (e == hipSuccess) e = dev_alloc(&plan->cells_t, 2 * cells);
-    if (e != hipSuccess) return cleanup(e);
-
-    const int lanes = std::min(pick_lanes_per_row(static_cast<float>(src.nnz) / src.rows) * 4, 64);
-    auto bucket = [&](int pass) -> hipError_t {
-        if (A) {
-            return pass == 0 ? launch_bucket_lanes<0>(lanes, A, *plan, cnt, nullptr, num_long, s)
-                             : launch_bucket_lanes<1>(lanes, A, *plan, cnt, offs, num_long, s);
-        }
+    std::vector<int> host_strip;
+    bool fold = true;
+    if (const char* env = std::getenv("SPMV_TILED_FOLD")) fold = env[0] != '0';
+    hipError_t e;
+    if (A) {
+        const CsrSource dev_src{A->d_row_ptrs, A->d_col_indices, A->d_values};
+        e = build_cells(dev_src, true, plan, true, &host_strip, s);
+    } else {
         const ELLMatrix* E = src.ell;
-        const int grid = (E->num_rows + kBlock - 1) / kBlock;
-        if (pass == 0) {
-            bucket_ell_kernel<0><<<grid, kBlock, 0, s>>>(E->num_rows, E->max_nnz_per_row, plan->num_tiles,
-                                                        plan->strip_cols, plan->tile_rows, E->d_col_indices,
-                                                        E->d_values, cnt, nullptr, nullptr, nullptr, nullptr);
-        } else {
-            bucket_ell_kernel<1><<<grid, kBlock, 0, s>>>(E->num_rows, E->max_nnz_per_row, plan->num_tiles,
-                                                        plan->strip_cols, plan->tile_rows, E->d_col_indices,
-                                                        E->d_values, cnt, offs, plan->a_val, plan->a_lcol,
-                                                        plan->a_lrow);
-        }
-        return hipGetLastError();
-    };
-
-    // pass 0: cell sizes + the list of long rows
-    e = hipMemsetAsync(cnt, 0, cells * sizeof(int), s);
-    if (e == hipSuccess) e = hipMemsetAsync(num_long, 0, sizeof(int), s);
-    if (e == hipSuccess) e = bucket(0);
-    if (e == hipSuccess) {
-        exclusive_scan_kernel<<<1, 1024, 0, s>>>(cnt, cells, offs);
-        e = hipGetLastError();
+        const EllSource dev_src{E->num_rows, E->max_nnz_per_row, E->d_col_indices, E->d_values};
+        e = build_cells(dev_src, false, plan, true, &host_strip, s);
     }
-    int totals[2] = {0, 0};   // entries in cells, long rows
-    if (e == hipSuccess) e = hipMemcpyAsync(&totals[0], offs + cells, sizeof(int), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(&totals[1], num_long, sizeof(int), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return cleanup(e);
-    plan->nnz = totals[0];
-    plan->num_long = totals[1];
-    {   // 64-entry chunks taken from a run per pass of phase 2: cover the mean run with some slack
+    int* strip_begin = plan->items;         // parked there by build_cells
+    plan->items = nullptr;
+    auto fail_with_strip = [&](hipError_t err) {
+        if (strip_begin) (void)hipFree(strip_begin);
+        return fail(err);
+    };
+    if (e != hipSuccess) return fail_with_strip(e);
+    {   // slots a lane takes per phase-2 load: 4 (16-byte loads) unless the runs are short
         const long long mean_run = plan->nnz / std::max<long long>(cells, 1);
-        // same-box A/B with the paired loads: 4 chunks win from ~130-entry runs on (C2 133: 54.7 -> 54.2 us,
-        // C4 168: 55.8 -> 54.4, C5 256: 532 -> 521), 2 chunks below (1/8 shard, 107: 84 vs 86.5)
-        plan->run_chunks = mean_run <= 48 ? 1 : (mean_run <= 120 ? 2 : 4);
-        if (const char* env = std::getenv("SPMV_TILED_CHUNKS")) {
+        plan->lane_entries = mean_run <= 160 ? 2 : 4;
+        if (const char* env = std::getenv("SPMV_TILED_LANE_ENTRIES")) {
             const int v = std::atoi(env);
-            if (v == 1 || v == 2 || v == 4) plan->run_chunks = v;
+            if (v == 2 || v == 4) plan->lane_entries = v;
         }
     }
 
@@ -926,6 +1403,8 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         // cut the long rows into wavefront-sized chunks (the list is short: <= nnz / long_row rows)
         std::vector<int> rows(plan->num_long);
         e = hipMemcpy(rows.data(), plan->long_rows, rows.size() * sizeof(int), hipMemcpyDeviceToHost);
+        std::sort(rows.begin(), rows.end());           // the device listed them in arrival order
+        if (e == hipSuccess) e = hipMemcpy(plan->long_rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice);
         std::vector<int> chunks;
         std::vector<int> all_ptrs;                       // many long rows: one bulk copy instead
         const int* host_ptrs = A->row_ptrs;
@@ -952,73 +1431,69 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         if (e == hipSuccess) e = dev_alloc(&plan->long_chunks, static_cast<long long>(chunks.size()));
         if (e == hipSuccess) e = hipMemcpy(plan->long_chunks, chunks.data(), chunks.size() * sizeof(int),
                                            hipMemcpyHostToDevice);
-        if (e != hipSuccess) return cleanup(e);
+        if (e == hipSuccess) e = dev_alloc(&plan->seed, plan->num_rows);
+        if (e == hipSuccess) e = hipMemsetAsync(plan->seed, 0, static_cast<size_t>(plan->num_rows) * sizeof(float), s);
+        if (e != hipSuccess) return fail_with_strip(e);
     }
 
-    // column-weight folding (see column_weight_probe_kernel): on unless SPMV_TILED_FOLD=0
-    bool fold = true;
-    if (const char* env = std::getenv("SPMV_TILED_FOLD")) fold = env[0] != '0';
+    // column-weight folding (see strip_weight_kernel): on unless SPMV_TILED_FOLD=0.  The first few strips
+    // alone settle it for arbitrary values (a column that occurs twice there already differs).
     if (fold && plan->nnz > 0) {
-        const int* src_cols = A ? A->d_col_indices : src.ell->d_col_indices;
-        const float* src_vals = A ? A->d_values : src.ell->d_values;
-        int* differs = num_long;                       // its count is on the host already: reuse the word
-        const int grid = static_cast<int>(std::min<long long>((src.nnz + kBlock - 1) / kBlock, 16384));
-        e = dev_alloc(&plan->col_weight, plan->num_cols);
-        if (e == hipSuccess) e = hipMemsetAsync(plan->col_weight, 0, static_cast<size_t>(plan->num_cols) * sizeof(float), s);
+        int* differs = nullptr;
+        e = dev_alloc(&differs, 1);
+        if (e == hipSuccess) e = dev_alloc(&plan->col_weight, plan->num_cols);
         if (e == hipSuccess) e = hipMemsetAsync(differs, 0, sizeof(int), s);
-        // first the leading 1 M entries only: with arbitrary values a column that occurs twice there
-        // already differs, and the two full passes (6 ms on C5) are skipped
         int host_differs = 1;
-        const long long sample = std::min<long long>(src.nnz, 1LL << 20);
-        for (long long count : {sample, static_cast<long long>(src.nnz)}) {
-            const int launch = static_cast<int>(std::min<long long>((count + kBlock - 1) / kBlock, grid));
-            if (e == hipSuccess) {
-                column_weight_probe_kernel<0><<<launch, kBlock, 0, s>>>(src_cols, src_vals, count, plan->col_weight, differs);
-                column_weight_probe_kernel<1><<<launch, kBlock, 0, s>>>(src_cols, src_vals, count, plan->col_weight, differs);
-                e = hipGetLastError();
+        auto probe = [&](int first, int count) {
+            switch (plan->strip_cols) {
+                case 4096:  strip_weight_kernel<4096><<<count, 1024, 0, s>>>(first, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
+                case 8192:  strip_weight_kernel<8192><<<count, 1024, 0, s>>>(first, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
+                case 16384: strip_weight_kernel<16384><<<count, 1024, 0, s>>>(first, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
+                default:    strip_weight_kernel<32768><<<count, 1024, 0, s>>>(first, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
             }
+        };
+        const int sample = std::min(plan->num_strips, 4);
+        for (int round = 0; round < 2 && e == hipSuccess; ++round) {
+            if (round == 0) {
+                probe(0, sample);
+            } else {
+                if (plan->num_strips > sample) probe(sample, plan->num_strips - sample);
+                if (plan->num_long_chunks > 0) {
+                    const int grid = (plan->num_long_chunks + kBlock / 64 - 1) / (kBlock / 64);
+                    long_row_weight_kernel<0><<<grid, kBlock, 0, s>>>(plan->long_chunks, plan->num_long_chunks, plan->csr_cols,
+                                                                   plan->csr_vals, plan->col_weight, differs);
+                    long_row_weight_kernel<1><<<grid, kBlock, 0, s>>>(plan->long_chunks, plan->num_long_chunks, plan->csr_cols,
+                                                                   plan->csr_vals, plan->col_weight, differs);
+                }
+                weight_finish_kernel<<<std::min(2048, (plan->num_cols + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+                    plan->col_weight, plan->num_cols);
+            }
+            e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpyAsync(&host_differs, differs, sizeof(int), hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
-            if (e != hipSuccess) return cleanup(e);
-            if (host_differs || count == src.nnz) break;
+            if (host_differs) break;
         }
+        if (differs) (void)hipFree(differs);
+        if (e != hipSuccess) return fail_with_strip(e);
         if (host_differs) {
             (void)hipFree(plan->col_weight);
             plan->col_weight = nullptr;
+        } else {
+            (void)hipFree(plan->a_val);           // folded: phase 1 reads weights, not values
+            plan->a_val = nullptr;
         }
     }
+    (void)hipFree(strip_begin);
+    strip_begin = nullptr;
 
-    if (!plan->col_weight) e = dev_alloc(&plan->a_val, plan->nnz);
-    // + 8: the paired / 16-byte loads of a run's last group may touch a few entries past the end
-    if (e == hipSuccess) e = dev_alloc(&plan->a_lcol, plan->nnz + 8);
-    if (e == hipSuccess) e = dev_alloc(&plan->a_lrow, plan->nnz + 8);
-    if (e == hipSuccess) e = dev_alloc(&plan->prod, plan->nnz + 8);
-    if (e == hipSuccess && plan->num_long > 0) {
-        e = dev_alloc(&plan->seed, plan->num_rows);
-        if (e == hipSuccess) e = hipMemsetAsync(plan->seed, 0, static_cast<size_t>(plan->num_rows) * sizeof(float), s);
-    }
-    if (e != hipSuccess) return cleanup(e);
-
-    // pass 1: scatter the short rows' entries into their cells
-    e = hipMemsetAsync(cnt, 0, cells * sizeof(int), s);
-    if (e == hipSuccess) e = bucket(1);
-    if (e == hipSuccess) {
-        const int grid = static_cast<int>(std::min<long long>((cells + kBlock) / kBlock, 4096));
-        cell_table_kernel<<<grid, kBlock, 0, s>>>(offs, plan->num_strips, plan->num_tiles,
-                                                reinterpret_cast<int2*>(plan->cells_t), strip_begin);
-        e = hipGetLastError();
-    }
-    std::vector<int> host_strip(plan->num_strips + 1);
-    if (e == hipSuccess) e = hipMemcpyAsync(host_strip.data(), strip_begin, host_strip.size() * sizeof(int),
-                                            hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return cleanup(e);
+    e = dev_alloc(&plan->prod, plan->nnz + 8);
+    if (e != hipSuccess) return fail(e);
 
     // phase-1 work items: every strip's range cut into EQUAL pieces of <= item_entries (enough
-    // pieces to fill the chip several times), piece boundaries on multiples of 4 entries
+    // pieces to fill the chip several times), piece boundaries on multiples of 8 slots
     const long long floor_entries = std::max<long long>(kMinItemEntries, plan->strip_cols);   // strip load <= 40 % of the stream
     int item_entries = static_cast<int>(std::min<long long>(
-        kMaxItemEntries, std::max<long long>(floor_entries, (plan->nnz / 2048 + 3) / 4 * 4)));
+        kMaxItemEntries, std::max<long long>(floor_entries, (plan->nnz / 2048 + 7) / 8 * 8)));
     if (const char* env = std::getenv("SPMV_TILED_ITEM")) item_entries = std::max(1024, std::atoi(env));
     std::vector<int> items;
     for (int strip = 0; strip < plan->num_strips; ++strip) {
@@ -1027,7 +1502,7 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         int b = begin;
         for (int part = 1; part <= parts; ++part) {
             int next = part == parts ? stop
-                                     : static_cast<int>(begin + static_cast<long long>(stop - begin) * part / parts) / 4 * 4;
+                                     : static_cast<int>(begin + static_cast<long long>(stop - begin) * part / parts) / 8 * 8;
             next = std::max(next, b);
             if (next == b && part != parts) continue;
             items.push_back(strip);
@@ -1041,8 +1516,12 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     if (e == hipSuccess && !items.empty()) {
         e = hipMemcpy(plan->items, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice);
     }
-    if (e != hipSuccess) return cleanup(e);
-    (void)cleanup(hipSuccess);
+    if (e != hipSuccess) return fail(e);
+
+    plan->plan_bytes = plan->nnz * (4 /*prod*/ + 2 + 1 + (plan->a_val ? 4 : 0)) + cells * 8 +
+                       (plan->col_weight ? 4LL * plan->num_cols : 0) + (plan->seed ? 4LL * plan->num_rows : 0) +
+                       12LL * plan->num_items + 12LL * plan->num_long_chunks;
+    plan->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     *out = plan;
     return hipSuccess;
 }

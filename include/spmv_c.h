@@ -196,8 +196,12 @@ int spmv_c_csr_has_tiled_plan(const spmv_c_csr* A);
  * when it would take it (use_texture), and the strip width / tile height it would use (host logic) */
 int spmv_c_tiled_shape(int64_t rows, int64_t cols, int64_t nnz, int32_t* strip_cols, int32_t* tile_rows);
 /* extension: the plan a matrix currently holds — out[8] = strip_cols, tile_rows, num_strips, num_tiles,
- * entries in cells, long rows, 64-entry chunks per phase-2 pass, long-row limit; returns 0 if none */
+ * slots in cells (entries + row-skip markers + padding), long rows, slots per lane per phase-2 load,
+ * long-row limit; returns 0 if none */
 int spmv_c_csr_tiled_info(const spmv_c_csr* A, int64_t out[8]);
+/* extension: what the plan cost — out[4] = build time in ms (host wall clock, allocations included),
+ * device bytes held, slots in cells, matrix entries in cells; returns 0 if the matrix has no plan */
+int spmv_c_csr_tiled_stats(const spmv_c_csr* A, double out[4]);
 /* extension: 1 when the matrix's plan folded its values into one weight per column (every stored
  * entry of a column bit-identical: adjacency / column-stochastic matrices), so that the tiled engine
  * streams no values; 0 otherwise or without a plan.  SPMV_TILED_FOLD=0 at build time disables it. */

@@ -8,6 +8,7 @@ constexpr int R = 8192;
 template <int MODE, bool RANDOM>
 __global__ __launch_bounds__(256) void k(float* out, int iters) {
     __shared__ float t[R];
+    double* td = reinterpret_cast<double*>(t);
     for (int i = threadIdx.x; i < R; i += 256) t[i] = 0.f;
     __syncthreads();
     unsigned s = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
@@ -27,6 +28,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
                 seen = got;
             }
         }
+        else if (MODE == 5) atomicAdd(&td[a & (R / 2 - 1)], 1.0);     // ds_add_f64 (R / 2 doubles = the same LDS bytes)
+        else if (MODE == 6) { float old = atomicAdd(&t[a], 1.0f); if (old == 0.123f) out[0] = old; }   // ds_add_rtn_f32
         else { float v = t[a]; if (v == 123.f) out[0] = v; }   // read only
     }
     __syncthreads();
@@ -52,6 +55,9 @@ int main() {
     run<0, false>("ds_add_f32 sequential", out);
     run<1, true>("ds_add_u32 random", out);
     run<1, false>("ds_add_u32 sequential", out);
+    run<5, true>("ds_add_f64 random", out);
+    run<5, false>("ds_add_f64 sequential", out);
+    run<6, true>("ds_add_rtn_f32 random", out);
     run<4, true>("cas float add random", out);
     run<4, false>("cas float add sequential", out);
     run<2, true>("read+write random", out);

@@ -172,20 +172,31 @@ def main():
     torch.cuda.synchronize()
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     achieved = local_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_file):
-        try:
-            traffic = json.load(open(pmc_file)).get("pr_step_kernel_bytes_per_launch")
-        except Exception:
-            traffic = None
     tiled = spmv.csr_has_tiled_plan(engine._A)
     plan_info = spmv.csr_tiled_info(engine._A)
-    step_kernels = ("tiled_expand_kernel + tiled_pagerank_reduce_kernel (LDS-tiled SpMV step, two launches)"
-                    if tiled else "pr_step_kernel (fused vector-CSR SpMV + PageRank update)")
+    # roofline.traffic is NOT measured by this run: it is the PMC figure of a separate rocprofv3 pass over this
+    # same command (tools/pmc_traffic.sh -> profiles/pmc_traffic.json; FETCH_SIZE x 2 + WRITE_SIZE, see
+    # MI355X_MICROARCH.md).  It is reported only while that file describes the plan shape that ran here.
+    traffic, traffic_source = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_file) and world == 1 and tiled:
+        try:
+            pmc = json.load(open(pmc_file))
+            same_shape = all(pmc.get("plan", {}).get(k) == plan_info.get(k)
+                             for k in ("strip_cols", "tile_rows", "num_strips", "num_tiles", "slots_in_cells"))
+            if same_shape:
+                traffic = pmc.get("pr_step_kernel_bytes_per_launch")
+                traffic_source = "profiles/pmc_traffic.json (%s)" % pmc.get("collected", "separate rocprofv3 --pmc passes")
+            else:
+                traffic_source = "profiles/pmc_traffic.json describes another plan shape: not reported"
+        except Exception:
+            traffic = None
+    step_kernels = ("tiled_expand_kernel + tiled_pagerank_reduce_kernel (two launches per step: bucketed-slot "
+                    "propagation-blocking engine, x strips and y tiles in LDS)"
+                    if tiled else "pr_step_kernel (fused vector-CSR direct-gather SpMV + PageRank update)")
     roofline = {"bound": "hbm", "kernel": step_kernels,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": local_bytes,
                 "tiled_plan": plan_info}
 
@@ -196,8 +207,14 @@ def main():
         "data": "synthetic (counter-based uniform random CSR generated in HBM, seed %d)" % args.seed,
         "config": {"workload": "csr_uniform_%dx%d_%d_per_row_pagerank_step" % (n, n, k), "rows": n, "cols": n,
                    "nnz": nnz_total, "avg_nnz_per_row": k,
-                   "kernel": "VECTOR_CSR with x staged through LDS tiles (fused PageRank step)" if tiled
-                             else "VECTOR_CSR direct gather (fused PageRank step)",
+                   "kernel": ("LDS-tiled engine (what SpMVConfig::use_texture selects for VECTOR_CSR on this matrix): a second, "
+                              "bucketed copy of the entries (7 B per slot + a 4 B product slot) streamed in two phases per step; "
+                              "the direct vector-CSR kernel on the CSR arrays is the row c5_10Mx16/vector of spmv_csr_api")
+                             if tiled else "VECTOR_CSR direct gather (fused PageRank step)",
+                   "plan_build_ms": plan_info.get("build_ms") if plan_info else None,
+                   "plan_bytes": plan_info.get("plan_bytes") if plan_info else None,
+                   "plan_note": "one-time per matrix, outside the timed region; break-even against the direct kernel "
+                                "after ~4 SpMVs (pagerank() starts on the direct kernel and builds it after 4 steps)",
                    "parallelism": "row-shard x%d%s" % (world, "" if world == 1 else
                        " + one RCCL all-gather per step (%d f32/rank, partial sums in the slice tails)" % layout.stride),
                    "exchange": exchange,
@@ -218,6 +235,7 @@ def main():
                                   "ms_per_iteration_incl_setup": round(t_full / max(full.iterations, 1) * 1e3, 3),
                                   "rank_sum": float(full.ranks.sum(dtype=np.float64))}
         result["spmv_csr_api"] = api_table(spmv, wl, engine, n, k, args.seed)
+        result["parity_report"] = parity_report(spmv, wl, args.seed)
         result["cpu_baseline"], result["cpu_baseline_all_cores"] = cpu_baseline(spmv, row_ptrs, cols_v, vals_v, n, nnz_total)
     elif rank == 0:
         result["cpu_baseline"] = None
@@ -353,6 +371,44 @@ def api_table(spmv, wl, engine, n, k, seed):
     x.release()
     y.release()
     return table
+
+
+def parity_report(spmv, wl, seed):
+    """Per config and kernel: the backward-error figure the tests gate on (|got - want| <= 1e-5 * max(|want|,
+    sum_j |a_ij x_j|)) next to the number of rows that would fail the PLAIN relative form 1e-5 * |want| (rows
+    whose terms cancel; any kernel that reorders a row's sum has them on signed data).  Checker: oracle/."""
+    oracle = importlib.import_module("oracle")
+    out = {}
+
+    def check(name, A, kernels):
+        rp, ci, va = A.to_host()
+        x = spmv.synth.vector(seed, 1, A.cols)
+        want = oracle.spmv_csr(rp, ci, va, x).astype(np.float64)
+        prod = np.abs(va.astype(np.float64) * x.astype(np.float64)[ci])
+        csum = np.concatenate([[0.0], np.cumsum(prod)])
+        abs_sum = csum[rp[1:].astype(np.int64)] - csum[rp[:-1].astype(np.int64)]
+        d_x, d_y = spmv.CudaBuffer(A.cols), spmv.CudaBuffer(A.rows)
+        d_x.copyFromHost(x, A.cols)
+        for kt, label in kernels:
+            r = spmv.spmv_csr(A.handle, d_x, d_y, spmv.SpMVConfig(kt % 10, 256, kt >= 10), A.cols)
+            assert r.error_code == 0
+            got = d_y.copyToHost(A.rows).astype(np.float64)
+            diff = np.abs(got - want)
+            out[f"{name}/{label}"] = {
+                "rows": int(A.rows),
+                "worst_backward_error": float(np.max(diff / np.maximum(np.maximum(np.abs(want), abs_sum), 1e-30))),
+                "rows_failing_plain_relative_1e-5": int(np.count_nonzero(diff > 1e-5 * np.abs(want))),
+                "worst_plain_relative_error": float(np.max(diff / np.maximum(np.abs(want), 1e-30)))}
+        d_x.release()
+        d_y.release()
+
+    A = wl.uniform_csr_device(seed, 1_000_000, 1_000_000, 16)
+    check("c2_1Mx16", A, [(11, "vector+lds_tiles"), (1, "vector"), (2, "merge"), (0, "scalar")])
+    A.close()
+    P = wl.power_law_csr_device(seed, 1_000_000, 1_000_000)
+    check("c4_1M_powerlaw", P, [(12, "merge+lds_tiles"), (2, "merge"), (1, "vector")])
+    P.close()
+    return out
 
 
 def cpu_baseline(spmv, row_ptrs, cols, vals, n, nnz):

@@ -674,10 +674,16 @@ def pagerank(adj_matrix, config=None) -> PageRankResult:
     if not raw.ranks:
         return PageRankResult(None, 0, 0.0, False)
     n = adj_matrix.contents.num_rows
-    ranks = np.ctypeslib.as_array(raw.ranks, shape=(n,)).copy() if n > 0 else np.empty(0, np.float32)
-    result = PageRankResult(ranks, raw.iterations, float(raw.final_residual), bool(raw.converged))
-    lib().spmv_c_pagerank_free(byref(raw))
-    return result
+    if n < (1 << 18):
+        ranks = np.ctypeslib.as_array(raw.ranks, shape=(n,)).copy() if n > 0 else np.empty(0, np.float32)
+        lib().spmv_c_pagerank_free(byref(raw))
+    else:
+        # large result: a view of the library's (pinned, pooled) array, handed back by pagerank_free when the
+        # numpy array is collected — no 4n-byte host copy
+        ranks = np.ctypeslib.as_array(raw.ranks, shape=(n,))
+        import weakref
+        weakref.finalize(ranks, lambda held=raw: lib().spmv_c_pagerank_free(byref(held)))
+    return PageRankResult(ranks, raw.iterations, float(raw.final_residual), bool(raw.converged))
 
 
 def pagerank_top_k(result: PageRankResult, num_nodes: int, k: int):

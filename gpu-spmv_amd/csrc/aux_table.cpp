@@ -25,6 +25,7 @@ std::unordered_map<const void*, EllAux*>& ell_table() {
 }
 
 void release(CsrAux* a) {
+    a->pagerank.release();
     if (a->d_tile_rows) (void)hipFree(a->d_tile_rows);
     if (a->d_carry_row) (void)hipFree(a->d_carry_row);
     if (a->d_carry_val) (void)hipFree(a->d_carry_val);
@@ -33,6 +34,17 @@ void release(CsrAux* a) {
 }
 
 } // namespace
+
+void PrWorkspace::release() {
+    for (void* p : {static_cast<void*>(r[0]), static_cast<void*>(r[1]), static_cast<void*>(mask), static_cast<void*>(partials),
+                    static_cast<void*>(sums), state, static_cast<void*>(dangling_count)}) {
+        if (p) (void)hipFree(p);
+    }
+    if (pinned_state) (void)hipHostFree(pinned_state);
+    if (pinned_ranks) (void)hipHostFree(pinned_ranks);
+    for (hipEvent_t e : seen) if (e) (void)hipEventDestroy(e);
+    *this = PrWorkspace();
+}
 
 CsrAux* aux_lookup(const void* key, bool create) {
     if (!key) return nullptr;
@@ -64,13 +76,25 @@ namespace {
 std::mutex g_build_lock;   // one plan build at a time (two threads may meet on the same matrix)
 }
 
+namespace {
+bool plan_matches(const TiledPlan* p, const CSRMatrix* A) {
+    return p->num_rows == A->num_rows && p->num_cols == A->num_cols && p->csr_nnz == A->nnz &&
+           p->csr_cols == A->d_col_indices && p->csr_vals == A->d_values;
+}
+}
+
+const TiledPlan* tiled_plan_if_cached(const CSRMatrix* A) {
+    if (!A || !A->d_row_ptrs) return nullptr;
+    std::lock_guard<std::mutex> building(g_build_lock);
+    CsrAux* aux = aux_lookup(A->d_row_ptrs, false);
+    return aux && aux->tiled && plan_matches(aux->tiled, A) ? aux->tiled : nullptr;
+}
+
 const TiledPlan* tiled_plan_for(const CSRMatrix* A, hipStream_t s) {
     if (!A || !A->d_row_ptrs || !tiled_eligible(A)) return nullptr;
     std::lock_guard<std::mutex> building(g_build_lock);
     CsrAux* aux = aux_lookup(A->d_row_ptrs, true);
-    if (aux->tiled && (aux->tiled->num_rows != A->num_rows || aux->tiled->num_cols != A->num_cols ||
-                       aux->tiled->csr_nnz != A->nnz || aux->tiled->csr_cols != A->d_col_indices ||
-                       aux->tiled->csr_vals != A->d_values)) {
+    if (aux->tiled && !plan_matches(aux->tiled, A)) {
         tiled_free(aux->tiled);       // header or arrays changed under the same row-pointer array
         aux->tiled = nullptr;
         aux->tiled_failed = false;

@@ -20,7 +20,29 @@ inline int code(SpMVError e) { return static_cast<int>(e); }
 // kernels precompute for a matrix lives here and is dropped by csr_free_gpu.
 struct TiledPlan;
 
+// Buffers of pagerank() kept with the matrix between calls (seven device allocations, a pinned mirror and
+// two events per call cost more than the iterations on a large graph), plus the dangling mask, which
+// depends on the matrix only.
+struct PrWorkspace {
+    size_t len = 0;                       // vector length everything below is sized for
+    float* r[2] = {nullptr, nullptr};     // the two rank vectors
+    unsigned char* mask = nullptr;        // dangling mask
+    bool mask_valid = false;
+    unsigned long long num_dangling = 0;
+    double* partials = nullptr;           // block partial sums / normalisation scratch
+    size_t partial_count = 0;
+    double* sums = nullptr;               // [2]
+    void* state = nullptr;                // PrState on the device
+    unsigned long long* dangling_count = nullptr;
+    void* pinned_state = nullptr;         // PrState[2], pinned host
+    float* pinned_ranks = nullptr;        // [len] pinned host staging for the copy out
+    hipEvent_t seen[2] = {nullptr, nullptr};
+    bool busy = false;                    // a call is using it (a concurrent call on the same matrix allocates its own)
+    void release();
+};
+
 struct CsrAux {
+    PrWorkspace pagerank;
     // row-length statistics computed once (host scan or device reduction)
     bool   have_stats = false;
     CSRStats stats{};
@@ -38,6 +60,8 @@ struct CsrAux {
 
 // the matrix's tiled plan (built on first call), or nullptr when not eligible / not buildable
 const TiledPlan* tiled_plan_for(const CSRMatrix* A, hipStream_t s);
+// the plan only if the matrix already holds a valid one (never builds)
+const TiledPlan* tiled_plan_if_cached(const CSRMatrix* A);
 
 CsrAux* aux_lookup(const void* key, bool create);
 void    aux_drop(const void* key);
@@ -62,6 +86,7 @@ hipError_t launch_csr_vector_ldsx(const CSRMatrix* A, const float* d_x, float* d
                                   int grid, hipStream_t s);
 hipError_t launch_csr_merge(const CSRMatrix* A, CsrAux* aux, const float* d_x, float* d_y,
                             hipStream_t s);
+hipError_t prepare_csr_merge(const CSRMatrix* A, CsrAux* aux, hipStream_t s);   // the merge tile table, ahead of a timed call
 hipError_t launch_ell(const ELLMatrix* A, const float* d_x, float* d_y, hipStream_t s);
 hipError_t launch_fill_zero(float* d_y, size_t n, hipStream_t s);
 hipError_t launch_ell_from_csr(const CSRMatrix* csr, int width, int* d_ell_cols, float* d_ell_vals,

@@ -537,31 +537,39 @@ hipError_t launch_csr_vector(const CSRMatrix* A, const float* d_x, float* d_y,
     }
 }
 
+// the tile table of the merge-path kernels: built on first use (or ahead of a timed call), cached with the matrix
+hipError_t prepare_csr_merge(const CSRMatrix* A, CsrAux* aux, hipStream_t s) {
+    const long long total = static_cast<long long>(A->num_rows) + A->nnz;
+    const int num_tiles = static_cast<int>((total + kMergeTile - 1) / kMergeTile);
+    if (num_tiles == 0 || !aux) return hipSuccess;
+    if (aux->num_tiles == num_tiles && aux->tile_items == kMergeTile && aux->d_tile_rows) return hipSuccess;
+    if (aux->d_tile_rows) (void)hipFree(aux->d_tile_rows);
+    if (aux->d_carry_row) (void)hipFree(aux->d_carry_row);
+    if (aux->d_carry_val) (void)hipFree(aux->d_carry_val);
+    aux->d_tile_rows = nullptr;
+    aux->d_carry_row = nullptr;
+    aux->d_carry_val = nullptr;
+    aux->num_tiles = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&aux->d_tile_rows), (num_tiles + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&aux->d_carry_row), num_tiles * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&aux->d_carry_val), num_tiles * sizeof(float));
+    if (e != hipSuccess) return e;
+    merge_partition_kernel<<<(num_tiles + 1 + kBlock - 1) / kBlock, kBlock, 0, s>>>(
+        A->num_rows, A->nnz, A->d_row_ptrs, num_tiles, aux->d_tile_rows);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    aux->num_tiles = num_tiles;
+    aux->tile_items = kMergeTile;
+    return hipSuccess;
+}
+
 hipError_t launch_csr_merge(const CSRMatrix* A, CsrAux* aux, const float* d_x, float* d_y,
                             hipStream_t s) {
     const long long total = static_cast<long long>(A->num_rows) + A->nnz;
     const int num_tiles = static_cast<int>((total + kMergeTile - 1) / kMergeTile);
     if (num_tiles == 0) return hipSuccess;
-
-    if (aux->num_tiles != num_tiles || aux->tile_items != kMergeTile || !aux->d_tile_rows) {
-        // first use for this matrix: allocate and fill the tile table (structure is static)
-        if (aux->d_tile_rows) (void)hipFree(aux->d_tile_rows);
-        if (aux->d_carry_row) (void)hipFree(aux->d_carry_row);
-        if (aux->d_carry_val) (void)hipFree(aux->d_carry_val);
-        aux->d_tile_rows = nullptr;
-        aux->d_carry_row = nullptr;
-        aux->d_carry_val = nullptr;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&aux->d_tile_rows), (num_tiles + 1) * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&aux->d_carry_row), num_tiles * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&aux->d_carry_val), num_tiles * sizeof(float));
-        if (e != hipSuccess) return e;
-        merge_partition_kernel<<<(num_tiles + 1 + kBlock - 1) / kBlock, kBlock, 0, s>>>(
-            A->num_rows, A->nnz, A->d_row_ptrs, num_tiles, aux->d_tile_rows);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        aux->num_tiles = num_tiles;
-        aux->tile_items = kMergeTile;
-    }
+    hipError_t prepared = prepare_csr_merge(A, aux, s);
+    if (prepared != hipSuccess) return prepared;
 
     merge_tile_kernel<<<num_tiles, kBlock, 0, s>>>(A->num_rows, A->nnz, A->d_row_ptrs,
                                                    A->d_col_indices, A->d_values, d_x,

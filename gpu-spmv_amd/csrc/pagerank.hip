@@ -30,6 +30,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace spmv {
@@ -422,6 +424,132 @@ struct Trace {
 
 } // namespace
 
+namespace {
+
+// PageRankResult::ranks of large graphs: pinned host arrays owned by the library and recycled by
+// pagerank_free(), so that the final device -> host copy runs at PCIe rate straight into the caller's array
+// (a fresh pageable 40 MB array costs ~7 ms in page faults and staging; the reference's contract is that
+// pagerank_free() releases the array, include/spmv/pagerank.h:36).  Small results stay plain new[] arrays.
+class ResultPool {
+public:
+    static constexpr size_t kMinPooled = 1u << 18;       // floats
+    float* take(size_t n) {
+        {
+            std::lock_guard<std::mutex> guard(lock_);
+            for (size_t i = 0; i < idle_.size(); ++i) {
+                if (idle_[i].second == n) {
+                    float* p = idle_[i].first;
+                    idle_.erase(idle_.begin() + i);
+                    lent_.push_back({p, n});
+                    return p;
+                }
+            }
+        }
+        float* p = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> guard(lock_);
+        lent_.push_back({p, n});
+        return p;
+    }
+    // true when `p` was one of ours (now back in the pool, or released when the pool is full)
+    bool give_back(float* p) {
+        std::pair<float*, size_t> entry{nullptr, 0};
+        {
+            std::lock_guard<std::mutex> guard(lock_);
+            for (size_t i = 0; i < lent_.size(); ++i) {
+                if (lent_[i].first == p) {
+                    entry = lent_[i];
+                    lent_.erase(lent_.begin() + i);
+                    break;
+                }
+            }
+            if (!entry.first) return false;
+            if (idle_.size() < 2) {
+                idle_.push_back(entry);
+                return true;
+            }
+        }
+        (void)hipHostFree(entry.first);
+        return true;
+    }
+    bool owns(const float* p) {
+        std::lock_guard<std::mutex> guard(lock_);
+        for (const auto& e : lent_) if (e.first == p) return true;
+        return false;
+    }
+
+private:
+    std::mutex lock_;
+    std::vector<std::pair<float*, size_t>> idle_, lent_;
+};
+
+ResultPool& result_pool() {
+    static ResultPool* pool = new ResultPool();      // never destroyed: results may outlive static teardown
+    return *pool;
+}
+
+// Claims the matrix's cached workspace (or, when another call holds it, a private one) and makes sure
+// it holds vectors of `len` elements and `partial_pairs` pairs of partial sums.
+class WorkspaceLease {
+public:
+    WorkspaceLease(const CSRMatrix* adj) {
+        detail::CsrAux* aux = detail::aux_lookup(adj->d_row_ptrs, true);
+        static std::mutex claim;
+        std::lock_guard<std::mutex> guard(claim);
+        if (aux && !aux->pagerank.busy) {
+            aux->pagerank.busy = true;
+            ws_ = &aux->pagerank;
+        } else {
+            ws_ = &own_;
+            private_ = true;
+        }
+    }
+    ~WorkspaceLease() {
+        if (private_) own_.release();
+        else ws_->busy = false;
+    }
+    detail::PrWorkspace* operator->() { return ws_; }
+
+    bool ensure(size_t len, size_t partial_count) {
+        detail::PrWorkspace& w = *ws_;
+        if (w.len != len) {
+            const bool keep_busy = w.busy;
+            w.release();
+            w.busy = keep_busy;
+            bool ok = hipMalloc(reinterpret_cast<void**>(&w.r[0]), len * sizeof(float)) == hipSuccess
+                   && hipMalloc(reinterpret_cast<void**>(&w.r[1]), len * sizeof(float)) == hipSuccess
+                   && hipMalloc(reinterpret_cast<void**>(&w.mask), len) == hipSuccess
+                   && hipMalloc(reinterpret_cast<void**>(&w.sums), 2 * sizeof(double)) == hipSuccess
+                   && hipMalloc(&w.state, sizeof(detail::PrState)) == hipSuccess
+                   && hipMalloc(reinterpret_cast<void**>(&w.dangling_count), sizeof(unsigned long long)) == hipSuccess
+                   && hipHostMalloc(&w.pinned_state, 2 * sizeof(detail::PrState)) == hipSuccess
+                   && hipHostMalloc(reinterpret_cast<void**>(&w.pinned_ranks), len * sizeof(float)) == hipSuccess
+                   && hipEventCreateWithFlags(&w.seen[0], hipEventDisableTiming) == hipSuccess
+                   && hipEventCreateWithFlags(&w.seen[1], hipEventDisableTiming) == hipSuccess;
+            if (!ok) return false;
+            w.len = len;
+        }
+        if (w.partial_count < partial_count) {
+            if (w.partials) (void)hipFree(w.partials);
+            w.partials = nullptr;
+            w.partial_count = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&w.partials), partial_count * sizeof(double)) != hipSuccess) return false;
+            w.partial_count = partial_count;
+        }
+        return true;
+    }
+
+private:
+    detail::PrWorkspace* ws_ = nullptr;
+    detail::PrWorkspace own_;
+    bool private_ = false;
+};
+
+} // namespace
+
 PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     PageRankResult result;
     if (!adj) return result;
@@ -430,7 +558,9 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     if (!config) config = &fallback;
 
     const int n = adj->num_rows;
-    result.ranks = new float[std::max(n, 0)];
+    if (static_cast<size_t>(std::max(n, 0)) >= ResultPool::kMinPooled) result.ranks = result_pool().take(static_cast<size_t>(n));
+    const bool pinned_result = result.ranks != nullptr;
+    if (!result.ranks) result.ranks = new float[std::max(n, 0)];
     const float start = n > 0 ? 1.0f / n : 0.0f;
     if (n <= 0) return result;
     // every exit that does not deliver computed ranks hands back the start vector (filled on the way
@@ -448,67 +578,24 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
 
     hipStream_t stream = detail::current_stream();
     using detail::PrState;
+    const Trace trace("pagerank");
 
-    DeviceArray<float> r_a, r_b, col_sums;
-    DeviceArray<unsigned char> mask;
-    DeviceArray<double> partials, sums;
-    DeviceArray<PrState> state;
-    DeviceArray<unsigned long long> dangling_count;
+    // Steps through the LDS-tiled engine pay once x has left the L2s — but its plan costs about as much
+    // as a few direct-gather steps, and max_iterations says nothing about how soon the loop converges
+    // (the 10 M-node uniform graph: 3 iterations).  So: a plan the matrix already holds is used from the
+    // first step; otherwise the loop starts on the direct kernel and builds the plan only once it has
+    // spent about one build's worth of time on direct steps (ski rental: never more than ~2x the better
+    // choice).  Estimates per stored entry, measured on C5: build 50 ps, direct step 17 ps, tiled step 3.3 ps.
+    const detail::TiledPlan* plan = detail::tiled_plan_if_cached(adj);
+    int build_plan_at = -1;
+    if (!plan && detail::tiled_eligible(adj)) {
+        build_plan_at = static_cast<int>(std::ceil(50.0 / (17.0 - 3.3)));            // = 4 direct steps
+        if (const char* env = std::getenv("SPMV_PR_PLAN_AFTER")) build_plan_at = std::max(0, std::atoi(env));
+        if (build_plan_at == 0) plan = detail::tiled_plan_for(adj, stream);
+    }
+
     // vectors are indexed by column during the SpMV and by row during the update
     const size_t len = static_cast<size_t>(std::max(n, adj->num_cols));
-    if (r_a.alloc(len) != hipSuccess || r_b.alloc(len) != hipSuccess ||
-        mask.alloc(len) != hipSuccess ||
-        sums.alloc(2) != hipSuccess || state.alloc(1) != hipSuccess ||
-        dangling_count.alloc(1) != hipSuccess) {
-        return result;
-    }
-
-    const Trace trace("pagerank");
-    bool ok = hipMemsetAsync(mask.ptr, 0, len, stream) == hipSuccess
-           && hipMemsetAsync(dangling_count.ptr, 0, sizeof(unsigned long long), stream) == hipSuccess
-           && detail::pr_fill(r_a.ptr, len, start, stream) == hipSuccess
-           && detail::pr_fill(r_b.ptr, len, start, stream) == hipSuccess;
-
-    // large x: the steps run through the LDS-tiled engine (plan cached with the matrix)
-    const detail::TiledPlan* plan = ok ? detail::tiled_plan_for(adj, stream) : nullptr;
-    trace.mark("buffers + plan");
-
-    // Dangling mask.  A plan with folded values knows every column's one stored value w (0 where the
-    // column has no entry): the reference's sequential fp32 column sum of k copies of w is 0 exactly
-    // when w == 0, so the mask is read off the weights.  Otherwise: host scan when host arrays exist
-    // (reference semantics), else atomic column sums on the device.
-    unsigned long long num_dangling = 0;
-    if (ok && plan && plan->col_weight) {
-        ok = detail::pr_mask_from_column_sums(plan->col_weight, std::min(n, adj->num_cols), mask.ptr,
-                                              dangling_count.ptr, stream) == hipSuccess
-          && hipMemcpyAsync(&num_dangling, dangling_count.ptr, sizeof(num_dangling),
-                            hipMemcpyDeviceToHost, stream) == hipSuccess
-          && hipStreamSynchronize(stream) == hipSuccess;
-    } else if (ok && adj->values && adj->col_indices && adj->row_ptrs) {
-        const std::vector<unsigned char> host_mask = dangling_mask_host(adj);
-        const size_t m = std::min(host_mask.size(), static_cast<size_t>(n));
-        for (size_t c = 0; c < m; ++c) num_dangling += host_mask[c];
-        ok = hipMemcpyAsync(mask.ptr, host_mask.data(), m, hipMemcpyHostToDevice, stream) == hipSuccess
-          && hipStreamSynchronize(stream) == hipSuccess;
-    } else if (ok) {
-        ok = col_sums.alloc(len) == hipSuccess
-          && hipMemsetAsync(col_sums.ptr, 0, len * sizeof(float), stream) == hipSuccess
-          && detail::pr_column_sums(adj->nnz, adj->d_col_indices, adj->d_values, adj->num_cols,
-                                    col_sums.ptr, stream) == hipSuccess
-          && detail::pr_mask_from_column_sums(col_sums.ptr, std::min(n, adj->num_cols), mask.ptr,
-                                              dangling_count.ptr, stream) == hipSuccess
-          && hipMemcpyAsync(&num_dangling, dangling_count.ptr, sizeof(num_dangling),
-                            hipMemcpyDeviceToHost, stream) == hipSuccess
-          && hipStreamSynchronize(stream) == hipSuccess;
-    }
-    if (!ok) return result;
-    trace.mark("dangling mask");
-
-    // dangling mass of the start vector: the same left-to-right fp32 sum as the host loop
-    PrState host_state{};
-    for (unsigned long long k = 0; k < num_dangling; ++k) host_state.dangling_sum += start;
-    ok = hipMemcpyAsync(state.ptr, &host_state, sizeof(PrState), hipMemcpyHostToDevice, stream) == hipSuccess;
-
     detail::PrShard shard;
     shard.local_rows = n;
     shard.row_offset = 0;
@@ -517,37 +604,96 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     shard.d_row_ptrs = adj->d_row_ptrs;
     shard.d_cols = adj->d_col_indices;
     shard.d_vals = adj->d_values;
-    shard.d_dangling = mask.ptr;
-    shard.d_state = state.ptr;
-    const int partial_pairs = detail::pr_shard_prepare(&shard, plan);
-    ok = ok && partials.alloc(std::max<size_t>(2 * static_cast<size_t>(partial_pairs), detail::kNormaliseBlocks)) == hipSuccess;
-    shard.d_block_partials = partials.ptr;
+    int partial_pairs = detail::pr_shard_prepare(&shard, plan);
+    if (build_plan_at > 0) {       // room for the tiled engine's partial sums too, should the plan arrive later
+        int w = 0, r = 0;
+        detail::tiled_shape_for(n, adj->num_cols, adj->nnz, &w, &r);
+        if (r > 0) partial_pairs = std::max(partial_pairs, (n + r - 1) / r);
+    }
+    WorkspaceLease ws(adj);
+    if (!ws.ensure(len, std::max<size_t>(2 * static_cast<size_t>(partial_pairs), detail::kNormaliseBlocks))) return result;
+    shard.d_dangling = ws->mask;
+    shard.d_state = static_cast<PrState*>(ws->state);
+    shard.d_block_partials = ws->partials;
+
+    bool ok = detail::pr_fill(ws->r[0], len, start, stream) == hipSuccess
+           && detail::pr_fill(ws->r[1], len, start, stream) == hipSuccess;
+    trace.mark("workspace + plan lookup");
+
+    // Dangling mask (kept with the matrix: it depends on the matrix only).  A plan with folded values knows
+    // every column's one stored value w (0 where the column has no entry): the reference's sequential fp32
+    // column sum of k copies of w is 0 exactly when w == 0, so the mask is read off the weights.  Otherwise:
+    // host scan when host arrays exist (reference semantics), else atomic column sums on the device.
+    if (ok && !ws->mask_valid) {
+        unsigned long long num_dangling = 0;
+        ok = hipMemsetAsync(ws->mask, 0, len, stream) == hipSuccess
+          && hipMemsetAsync(ws->dangling_count, 0, sizeof(unsigned long long), stream) == hipSuccess;
+        if (ok && plan && plan->col_weight) {
+            ok = detail::pr_mask_from_column_sums(plan->col_weight, std::min(n, adj->num_cols), ws->mask,
+                                                  ws->dangling_count, stream) == hipSuccess
+              && hipMemcpyAsync(&num_dangling, ws->dangling_count, sizeof(num_dangling),
+                                hipMemcpyDeviceToHost, stream) == hipSuccess
+              && hipStreamSynchronize(stream) == hipSuccess;
+        } else if (ok && adj->values && adj->col_indices && adj->row_ptrs) {
+            const std::vector<unsigned char> host_mask = dangling_mask_host(adj);
+            const size_t m = std::min(host_mask.size(), static_cast<size_t>(n));
+            for (size_t c = 0; c < m; ++c) num_dangling += host_mask[c];
+            ok = hipMemcpyAsync(ws->mask, host_mask.data(), m, hipMemcpyHostToDevice, stream) == hipSuccess
+              && hipStreamSynchronize(stream) == hipSuccess;
+        } else if (ok) {
+            DeviceArray<float> col_sums;
+            ok = col_sums.alloc(len) == hipSuccess
+              && hipMemsetAsync(col_sums.ptr, 0, len * sizeof(float), stream) == hipSuccess
+              && detail::pr_column_sums(adj->nnz, adj->d_col_indices, adj->d_values, adj->num_cols,
+                                        col_sums.ptr, stream) == hipSuccess
+              && detail::pr_mask_from_column_sums(col_sums.ptr, std::min(n, adj->num_cols), ws->mask,
+                                                  ws->dangling_count, stream) == hipSuccess
+              && hipMemcpyAsync(&num_dangling, ws->dangling_count, sizeof(num_dangling),
+                                hipMemcpyDeviceToHost, stream) == hipSuccess
+              && hipStreamSynchronize(stream) == hipSuccess;
+        }
+        if (ok) {
+            ws->num_dangling = num_dangling;
+            ws->mask_valid = true;
+        }
+    }
+    if (!ok) return result;
+    trace.mark("dangling mask");
+
+    // dangling mass of the start vector: the same left-to-right fp32 sum as the host loop
+    PrState host_state{};
+    for (unsigned long long k = 0; k < ws->num_dangling; ++k) host_state.dangling_sum += start;
+    ok = hipMemcpyAsync(ws->state, &host_state, sizeof(PrState), hipMemcpyHostToDevice, stream) == hipSuccess;
 
     // Pinned mirrors of the device state, two deep: the host enqueues step k+1
     // before it looks at the outcome of step k.
-    PrState* pinned = nullptr;
-    hipEvent_t seen[2] = {nullptr, nullptr};
-    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&pinned), 2 * sizeof(PrState)) == hipSuccess
-            && hipEventCreateWithFlags(&seen[0], hipEventDisableTiming) == hipSuccess
-            && hipEventCreateWithFlags(&seen[1], hipEventDisableTiming) == hipSuccess;
-
-    float* bufs[2] = {r_a.ptr, r_b.ptr};
+    PrState* pinned = static_cast<PrState*>(ws->pinned_state);
+    float* bufs[2] = {ws->r[0], ws->r[1]};
     for (int iter = 0; ok && iter < config->max_iterations; ++iter) {
+        if (!plan && iter == build_plan_at) {
+            // enough direct steps paid: switch to the tiled engine for the rest (the queue is drained first:
+            // the outcome of every enqueued step is known, so nothing is built for a loop that has converged)
+            ok = hipStreamSynchronize(stream) == hipSuccess;
+            if (ok && iter >= 1 && pinned[(iter - 1) & 1].done) break;
+            plan = ok ? detail::tiled_plan_for(adj, stream) : nullptr;
+            if (plan) (void)detail::pr_shard_prepare(&shard, plan);
+            trace.mark("plan build (after direct steps)");
+        }
         const float* r_old = bufs[iter & 1];
         float* r_new = bufs[(iter + 1) & 1];
-        ok = detail::pr_step(shard, r_old, r_new, config->damping_factor, detail::PushTargets{}, stream) == hipSuccess
+        ok = ok && detail::pr_step(shard, r_old, r_new, config->damping_factor, detail::PushTargets{}, stream) == hipSuccess
           && detail::pr_reduce_commit(shard, config->tolerance, stream) == hipSuccess
-          && hipMemcpyAsync(&pinned[iter & 1], state.ptr, sizeof(PrState),
+          && hipMemcpyAsync(&pinned[iter & 1], ws->state, sizeof(PrState),
                             hipMemcpyDeviceToHost, stream) == hipSuccess
-          && hipEventRecord(seen[iter & 1], stream) == hipSuccess;
+          && hipEventRecord(ws->seen[iter & 1], stream) == hipSuccess;
         if (ok && iter >= 1) {
-            ok = hipEventSynchronize(seen[(iter - 1) & 1]) == hipSuccess;
+            ok = hipEventSynchronize(ws->seen[(iter - 1) & 1]) == hipSuccess;
             if (ok && pinned[(iter - 1) & 1].done) break;
         }
     }
 
     if (ok) {
-        ok = hipMemcpyAsync(&host_state, state.ptr, sizeof(PrState), hipMemcpyDeviceToHost, stream) == hipSuccess
+        ok = hipMemcpyAsync(&host_state, ws->state, sizeof(PrState), hipMemcpyDeviceToHost, stream) == hipSuccess
           && hipStreamSynchronize(stream) == hipSuccess;
     }
     trace.mark("iterations");
@@ -559,21 +705,49 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
         // Final renormalisation on the device before the copy: r /= sum(r), the sum accumulated in
         // double (the reference's fp32 running sum loses digits at n ~ 1e7).
         float* last = bufs[host_state.iterations & 1];
-        ok = detail::pr_normalise(last, static_cast<size_t>(n), partials.ptr, stream) == hipSuccess
-          && hipMemcpyAsync(result.ranks, last, static_cast<size_t>(n) * sizeof(float),
-                            hipMemcpyDeviceToHost, stream) == hipSuccess
-          && hipStreamSynchronize(stream) == hipSuccess;
+        ok = detail::pr_normalise(last, static_cast<size_t>(n), ws->partials, stream) == hipSuccess;
+        // copy out: device -> pinned staging at PCIe rate, then into the caller's (pageable, freshly
+        // allocated) array; SPMV_PR_COPY=direct hands the pageable array to the runtime instead
+        static const bool direct_copy = [] {
+            const char* env = std::getenv("SPMV_PR_COPY");
+            return env && env[0] == 'd';
+        }();
+        const size_t bytes = static_cast<size_t>(n) * sizeof(float);
+        if (ok && (direct_copy || pinned_result)) {
+            ok = hipMemcpyAsync(result.ranks, last, bytes, hipMemcpyDeviceToHost, stream) == hipSuccess
+              && hipStreamSynchronize(stream) == hipSuccess;
+        } else if (ok) {
+            // in pieces, so that the host copy of piece k runs while piece k + 1 crosses PCIe
+            const size_t piece = 4u << 20;          // floats
+            size_t done = 0;
+            hipEvent_t landed[2] = {ws->seen[0], ws->seen[1]};
+            size_t issued = 0;
+            int turn = 0;
+            while (ok && done < static_cast<size_t>(n)) {
+                while (ok && issued < static_cast<size_t>(n) && issued < done + 2 * piece) {
+                    const size_t count = std::min(piece, static_cast<size_t>(n) - issued);
+                    ok = hipMemcpyAsync(ws->pinned_ranks + issued, last + issued, count * sizeof(float),
+                                        hipMemcpyDeviceToHost, stream) == hipSuccess
+                      && hipEventRecord(landed[turn & 1], stream) == hipSuccess;
+                    issued += count;
+                    ++turn;
+                }
+                const size_t count = std::min(piece, static_cast<size_t>(n) - done);
+                const int which = static_cast<int>((done / piece) & 1);
+                ok = ok && hipEventSynchronize(landed[which]) == hipSuccess;
+                if (ok) std::memcpy(result.ranks + done, ws->pinned_ranks + done, count * sizeof(float));
+                done += count;
+            }
+        }
     }
     trace.mark("normalise + copy out");
-    if (pinned) (void)hipHostFree(pinned);
-    for (hipEvent_t e : seen) if (e) (void)hipEventDestroy(e);
     start_vector.armed = !ok;
     return result;
 }
 
 void pagerank_free(PageRankResult* result) {
     if (result && result->ranks) {
-        delete[] result->ranks;
+        if (!result_pool().give_back(result->ranks)) delete[] result->ranks;
         result->ranks = nullptr;
     }
 }

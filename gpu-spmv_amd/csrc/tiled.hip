@@ -98,9 +98,10 @@ __host__ inline int xcd_grid(int count) { return (count + kXcds - 1) / kXcds * k
 
 // ------------------------------------------------------------------ plan building ----
 constexpr int kSkip = 255;                  // row-delta byte: advance 255 rows, no entry
-constexpr int kBuildBlock = 512;            // threads of a builder workgroup
-constexpr int kBuildLdsSmall = 72 * 1024;   // dynamic LDS of a builder workgroup (two per CU) ...
-constexpr int kBuildLdsLarge = 150 * 1024;  // ... or one per CU when the strips are many
+constexpr int kBuildBlock = 1024;           // threads of a builder workgroup
+constexpr int kBuildRowCache = 1024;        // row offsets of the batch kept in LDS for the entry -> row search
+constexpr int kBuildLdsSmall = 70 * 1024;   // dynamic LDS of a builder workgroup (two per CU, next to 8 KiB static) ...
+constexpr int kBuildLdsLarge = 148 * 1024;  // ... or one per CU when the strips are many
 constexpr int kBuildBinWords = 5;           // LDS ints per strip: start, cursor, escapes, first|last, spare
 constexpr int kBuildEntryBytes = 14;        // LDS bytes per entry: key 4, value 4, bin 2, rank 2, markers|delta 2
 constexpr int kMaxBuildStrips = 3072;
@@ -114,14 +115,8 @@ struct CsrSource {
     __device__ __forceinline__ long long offset(int row) const { return row_ptrs[row]; }
     __device__ __forceinline__ int col(long long j) const { return cols[j]; }
     __device__ __forceinline__ float val(long long j) const { return vals[j]; }
-    // the row in [lo, hi) that holds entry j (offset(lo) <= j < offset(hi))
-    __device__ __forceinline__ int row_of(long long j, int lo, int hi) const {
-        while (hi - lo > 1) {
-            const int mid = lo + (hi - lo) / 2;
-            if (row_ptrs[mid] <= j) lo = mid; else hi = mid;
-        }
-        return lo;
-    }
+    static constexpr bool kSearchRows = true;      // an entry's row comes from a search over the row offsets
+    __device__ __forceinline__ int direct_row(long long) const { return 0; }
 };
 struct EllSource {
     int rows, width;
@@ -131,9 +126,10 @@ struct EllSource {
     __device__ __forceinline__ long long slot(long long j, int row) const {
         return (j - static_cast<long long>(row) * width) * rows + row;
     }
-    __device__ __forceinline__ int row_of(long long j, int, int) const { return static_cast<int>(j / width); }
-    __device__ __forceinline__ int col(long long j) const { return cols[slot(j, row_of(j, 0, 0))]; }
-    __device__ __forceinline__ float val(long long j) const { return vals[slot(j, row_of(j, 0, 0))]; }
+    static constexpr bool kSearchRows = false;     // rows have a fixed width
+    __device__ __forceinline__ int direct_row(long long j) const { return static_cast<int>(j / width); }
+    __device__ __forceinline__ int col(long long j) const { return cols[slot(j, direct_row(j))]; }
+    __device__ __forceinline__ float val(long long j) const { return vals[slot(j, direct_row(j))]; }
 };
 
 struct BuildShape {
@@ -210,6 +206,7 @@ void batch_sort_kernel(Src src, BuildShape sh, int num_batches, int capacity,
                        int* __restrict__ long_rows, int* __restrict__ num_long) {
     extern __shared__ int build_lds[];
     __shared__ int s_partial[kBuildBlock];
+    __shared__ int s_row_cache[kBuildRowCache + 1];
     __shared__ int s_overflow;
     const int batch = xcd_contiguous(blockIdx.x, num_batches);
     if (batch < 0) return;
@@ -238,7 +235,28 @@ void batch_sort_kernel(Src src, BuildShape sh, int num_batches, int capacity,
         bin_ends[i] = 0;
     }
     if (threadIdx.x == 0) s_overflow = 0;
+    // entry -> row: binary search over the batch's row offsets, staged in LDS when the batch has few enough rows
+    const bool rows_cached = Src::kSearchRows && row1 - row0 <= kBuildRowCache;
+    if (rows_cached) {
+        for (int r = row0 + threadIdx.x; r <= row1; r += kBuildBlock) s_row_cache[r - row0] = static_cast<int>(src.offset(r));
+    }
     __syncthreads();
+    auto row_of = [&](long long j) -> int {
+        if (!Src::kSearchRows) return src.direct_row(j);
+        int lo = row0, hi = row1;                  // offset(lo) <= j < offset(hi)
+        if (rows_cached) {
+            while (hi - lo > 1) {
+                const int mid = lo + (hi - lo) / 2;
+                if (s_row_cache[mid - row0] <= j) lo = mid; else hi = mid;
+            }
+        } else {
+            while (hi - lo > 1) {
+                const int mid = lo + (hi - lo) / 2;
+                if (src.offset(mid) <= j) lo = mid; else hi = mid;
+            }
+        }
+        return lo;
+    };
 
     // Every short-row entry of the batch, flat over the batch's entry range: coalesced loads, four in
     // flight per thread.  The entry's row is looked up only where it is needed.
@@ -259,7 +277,7 @@ void batch_sort_kernel(Src src, BuildShape sh, int num_batches, int capacity,
     };
     // -1 for an entry of a long row (PASS 0 also lists the row, once, at its first entry)
     auto short_row_of = [&](long long j) {
-        const int row = src.row_of(j, row0, row1);
+        const int row = row_of(j);
         if (!sh.any_long) return row;
         const long long begin = src.offset(row);
         if (src.offset(row + 1) - begin <= sh.long_row) return row;
@@ -303,7 +321,7 @@ void batch_sort_kernel(Src src, BuildShape sh, int num_batches, int capacity,
 
     // ---- fill the bins (order inside a bin is arbitrary here; the ranking below fixes it)
     for_each_entry([&](long long j, int c) {
-        const int row = PASS == 0 && sh.any_long ? src.row_of(j, row0, row1) : short_row_of(j);
+        const int row = PASS == 0 && sh.any_long ? row_of(j) : short_row_of(j);
         if (sh.any_long) {
             if (PASS == 0) {       // (the histogram pass has listed the long rows already)
                 if (src.offset(row + 1) - src.offset(row) > sh.long_row) return;
@@ -568,13 +586,14 @@ void cell_padding_kernel(const int* __restrict__ cell_slots, const int* __restri
 constexpr unsigned int kNoWeight = 0x7FC0BEEFu;       // a NaN payload no arithmetic produces
 template <int W>
 __global__ __launch_bounds__(1024)
-void strip_weight_kernel(int first_strip, const int* __restrict__ strip_begin, int num_cols,
+void strip_weight_kernel(int first_strip, int slot_limit, const int* __restrict__ strip_begin, int num_cols,
                          const float* __restrict__ a_val, const unsigned short* __restrict__ a_lcol,
                          const unsigned char* __restrict__ a_drow,
                          float* __restrict__ weight, int* __restrict__ differs) {
     __shared__ float ws[W];
     const int strip = first_strip + blockIdx.x;
-    const int begin = strip_begin[strip], end = strip_begin[strip + 1];
+    const int begin = strip_begin[strip];
+    const int end = static_cast<int>(min(static_cast<long long>(strip_begin[strip + 1]), static_cast<long long>(begin) + slot_limit));
     for (int i = threadIdx.x; i < W; i += 1024) ws[i] = __uint_as_float(kNoWeight);
     __syncthreads();
     for (int q = begin + threadIdx.x; q < end; q += 1024) {
@@ -1444,20 +1463,22 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         if (e == hipSuccess) e = dev_alloc(&plan->col_weight, plan->num_cols);
         if (e == hipSuccess) e = hipMemsetAsync(differs, 0, sizeof(int), s);
         int host_differs = 1;
-        auto probe = [&](int first, int count) {
+        auto probe = [&](int first, int count, int limit) {
             switch (plan->strip_cols) {
-                case 4096:  strip_weight_kernel<4096><<<count, 1024, 0, s>>>(first, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
-                case 8192:  strip_weight_kernel<8192><<<count, 1024, 0, s>>>(first, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
-                case 16384: strip_weight_kernel<16384><<<count, 1024, 0, s>>>(first, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
-                default:    strip_weight_kernel<32768><<<count, 1024, 0, s>>>(first, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
+                case 4096:  strip_weight_kernel<4096><<<count, 1024, 0, s>>>(first, limit, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
+                case 8192:  strip_weight_kernel<8192><<<count, 1024, 0, s>>>(first, limit, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
+                case 16384: strip_weight_kernel<16384><<<count, 1024, 0, s>>>(first, limit, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
+                default:    strip_weight_kernel<32768><<<count, 1024, 0, s>>>(first, limit, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
             }
         };
-        const int sample = std::min(plan->num_strips, 4);
+        // round 0: the first 32 K slots of up to 64 strips (with arbitrary values some column repeats there and
+        // the matter is settled); round 1: everything
+        const int sample = std::min(plan->num_strips, 64);
         for (int round = 0; round < 2 && e == hipSuccess; ++round) {
             if (round == 0) {
-                probe(0, sample);
+                probe(0, sample, 32768);
             } else {
-                if (plan->num_strips > sample) probe(sample, plan->num_strips - sample);
+                probe(0, plan->num_strips, 0x7fffffff);
                 if (plan->num_long_chunks > 0) {
                     const int grid = (plan->num_long_chunks + kBlock / 64 - 1) / (kBlock / 64);
                     long_row_weight_kernel<0><<<grid, kBlock, 0, s>>>(plan->long_chunks, plan->num_long_chunks, plan->csr_cols,

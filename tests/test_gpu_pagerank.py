@@ -243,6 +243,26 @@ def test_pagerank_through_the_tiled_engine(gpu, oracle):
     gpu.csr_destroy(A)
 
 
+def test_pagerank_switches_to_the_tiled_engine_mid_run(gpu, oracle):
+    """A matrix without a cached plan starts on the direct-gather step and switches to the tiled engine once
+    it has spent about a plan's worth of time (SPMV_PR_PLAN_AFTER steps; default 4): same answer as the
+    oracle whether the switch comes after 0, 2 or 4 steps, or never (converged / ran out of steps first)."""
+    import os
+    n = 300_000
+    rp, ci, va = graph(gpu, n, 8, 33, dangling=(2, 150_000))
+    try:
+        for after, steps, expect_plan in (("2", 100, True), ("0", 100, True), ("4", 3, False), ("4", 100, True)):
+            os.environ["SPMV_PR_PLAN_AFTER"] = after
+            A = upload(gpu, rp, ci, va, n)
+            tol = 1e-6 if steps == 100 else 0.0
+            r = gpu.pagerank(A, gpu.PageRankConfig(0.85, tol, steps))
+            assert bool(gpu.csr_has_tiled_plan(A)) == expect_plan, (after, steps)
+            assert_parity(gpu, oracle, A, rp, ci, va, n, r, tolerance=tol, max_iterations=steps)
+            gpu.csr_destroy(A)
+    finally:
+        del os.environ["SPMV_PR_PLAN_AFTER"]
+
+
 def test_repeated_calls_on_a_power_law_graph_with_long_rows(gpu, oracle):
     """In-degrees follow a power law, so some rows are too long for the cells of the tiled engine: the
     first few thousand are summed through LDS accumulators in phase 1, the rest by the direct path,
@@ -284,8 +304,10 @@ def test_config5_pagerank_full_size_against_the_oracle(gpu, oracle):
     r = gpu.pagerank(A.handle, gpu.PageRankConfig(0.85, 1e-6, 100))
     assert r.converged and r.final_residual < 1e-6 and 2 <= r.iterations <= 100
     assert (r.ranks >= 0).all() and abs(float(r.ranks.sum(dtype=np.float64)) - 1.0) < 1e-4
-    info = gpu.csr_tiled_info(A.handle)
-    assert info is not None and info.get("values_folded")
+    # this graph converges before the loop has spent a plan's worth of time on direct steps, so the first call
+    # never builds one; the fixed-k runs below force the tiled engine from step 0
+    assert not gpu.csr_has_tiled_plan(A.handle)
+    os.environ["SPMV_PR_PLAN_AFTER"] = "0"
 
     rp, ci, va = A.to_host()
     k = 2
@@ -293,6 +315,8 @@ def test_config5_pagerank_full_size_against_the_oracle(gpu, oracle):
     assert iters == k
     fixed = gpu.pagerank(A.handle, gpu.PageRankConfig(0.85, 0.0, k))
     assert fixed.iterations == k
+    info = gpu.csr_tiled_info(A.handle)
+    assert info is not None and info.get("values_folded")
     compare(fixed.ranks, want)                                        # folded plan
     # the converged run, too: the oracle converges on this matrix within a handful of steps
     want_c, iters_c, _, conv_c = oracle.pagerank(rp, ci, va, num_cols=n, wide_sums=True)
@@ -309,6 +333,7 @@ def test_config5_pagerank_full_size_against_the_oracle(gpu, oracle):
         assert info is not None and not info.get("values_folded")
         compare(general.ranks, want)                                  # general plan
     finally:
+        del os.environ["SPMV_PR_PLAN_AFTER"]
         if previous is None:
             del os.environ["SPMV_TILED_FOLD"]
         else:

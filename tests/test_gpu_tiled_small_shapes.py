@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 
 
 def test_small_and_awkward_shapes_through_the_tiled_engine(gpu):
-    env = dict(os.environ, SPMV_TILED_MIN_COLS="1", SPMV_TILED_MIN_NNZ="1")
+    # SPMV_PR_PLAN_AFTER=0: pagerank() builds the tiled plan before its first step (by default a matrix
+    # without a plan starts on the direct kernel, see test_pagerank_switches_to_the_tiled_engine_mid_run)
+    env = dict(os.environ, SPMV_TILED_MIN_COLS="1", SPMV_TILED_MIN_NNZ="1", SPMV_PR_PLAN_AFTER="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tiled_small_shapes_worker.py")],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]

@@ -37,6 +37,14 @@ def main():
             total += kernels[k]["bytes"]
         out[variant] = {"kernels_avg_per_launch": kernels, "bytes_per_step": int(total)}
     out["pr_step_kernel_bytes_per_launch"] = out["general"]["bytes_per_step"]     # what bench.py reports as roofline.traffic
+    # the plan shape the passes ran on (bench.py reports the traffic only for the same shape) and when
+    for line in open(os.path.join(SRC, "general_fetch.log")):
+        if line.startswith("{"):
+            plan = json.loads(line)["roofline"]["tiled_plan"]
+            out["plan"] = {k: plan[k] for k in ("strip_cols", "tile_rows", "num_strips", "num_tiles", "slots_in_cells")}
+    import datetime
+    out["collected"] = "tools/pmc_traffic.sh, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s" % (
+        datetime.date.today().isoformat())
     out["note"] = ("sum over the two launches of one PageRank step (tiled_expand_kernel + tiled_pagerank_reduce_kernel); "
                    "bench.py's headline runs the general path")
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)

@@ -53,6 +53,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -832,6 +833,7 @@ __device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_in
 
     typedef float prod_t __attribute__((ext_vector_type(E)));
     typedef unsigned int delta_word_t;
+    constexpr int kWords = (E + 3) / 4;
     // (phase 2 is bound by vector-instruction issue once its loads are wide: rocprofv3 counted ~160 VALU
     // instructions per 128-slot run chunk in a first version, 85 % of the kernel's cycles.  Hence: run
     // geometry kept in scalar registers (v_readlane, not ds_bpermute), addresses as scalar base + one shared
@@ -859,7 +861,7 @@ __device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_in
         int done, longest;                 // wave-uniform
         bool valid;
         prod_t p[kRuns];
-        delta_word_t d[kRuns];
+        delta_word_t d[kRuns][kWords];     // E delta bytes (E = 2: the low half of one word)
     };
     int group = run_lo;                    // first run of the group opened next
     auto open_group = [&](Pass& ps) {
@@ -897,14 +899,21 @@ __device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_in
         const unsigned int i = static_cast<unsigned int>(ps.done) + E * lane;
 #pragma unroll
         for (int j = 0; j < kRuns; ++j) {
-            // lanes past the run's end re-read its last group (same cache line, no extra traffic); masked below
-            const unsigned int last = static_cast<unsigned int>(max(ps.len[j] - E, 0));
+            // lanes past the run's end re-read its last 4 slots (same cache line, no extra traffic) and a lane
+            // that straddles the end (E = 8, length 4 mod 8) reads 4 slots of the next cell: both masked below
+            const unsigned int last = static_cast<unsigned int>(max(ps.len[j] - 4, 0));
             const unsigned int at = min(i, last);
             const char* products = reinterpret_cast<const char*>(prod + ps.begin[j]);
             const char* deltas = reinterpret_cast<const char*>(a_drow + ps.begin[j]);
             ps.p[j] = *reinterpret_cast<const prod_t*>(products + static_cast<size_t>(at << 2));
-            if (E == 4) ps.d[j] = *reinterpret_cast<const unsigned int*>(deltas + static_cast<size_t>(at));
-            else        ps.d[j] = *reinterpret_cast<const unsigned short*>(deltas + static_cast<size_t>(at));
+            if (E == 2) {
+                ps.d[j][0] = *reinterpret_cast<const unsigned short*>(deltas + static_cast<size_t>(at));
+            } else {
+#pragma unroll
+                for (int w = 0; w < kWords; ++w) {
+                    ps.d[j][w] = *reinterpret_cast<const unsigned int*>(deltas + static_cast<size_t>(at) + 4 * w);
+                }
+            }
         }
     };
 
@@ -915,14 +924,18 @@ __device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_in
         for (int j = 0; j < kRuns; ++j) {
             if (ps.done == 0) row_base[j] = 0;
             if (ps.done >= ps.len[j]) continue;             // wave-uniform
-            // lanes past the run's end see skip markers only (the run ends in this chunk, so what they add to
-            // the scan is never used)
-            const unsigned int word = i < static_cast<unsigned int>(ps.len[j]) ? ps.d[j] : 0xFFFFFFFFu;
+            // slots past the run's end become skip markers (the run ends in this chunk, so what they add to
+            // the scan is never used): whole words, since lengths and lane offsets are multiples of 4 (E >= 4)
+            unsigned int word[kWords];
+#pragma unroll
+            for (int w = 0; w < kWords; ++w) {
+                word[w] = i + 4 * w < static_cast<unsigned int>(ps.len[j]) ? ps.d[j][w] : 0xFFFFFFFFu;
+            }
             int delta[E], upto[E];
             int sum = 0;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                delta[e] = (word >> (8 * e)) & 0xFF;
+                delta[e] = (word[e / 4] >> (8 * (e % 4))) & 0xFF;
                 sum += delta[e];
                 upto[e] = sum;
             }
@@ -1088,15 +1101,6 @@ hipError_t launch_expand(const TiledPlan& plan, const float* d_x, const PrState*
     }
 }
 
-// threads per phase-2 workgroup (two workgroups per CU either way): 1024 = 32 wavefronts per CU
-int reduce_block() {
-    static const int block = [] {
-        const char* env = std::getenv("SPMV_TILED_REDUCE_BLOCK");
-        return env && std::atoi(env) == 512 ? 512 : 1024;
-    }();
-    return block;
-}
-
 template <int BLOCK, int E, int kRuns>
 hipError_t launch_reduce_as(const TiledPlan& plan, float* d_y, hipStream_t s) {
     const size_t lds = static_cast<size_t>(plan.tile_rows) * sizeof(double);
@@ -1110,10 +1114,11 @@ hipError_t launch_reduce_as(const TiledPlan& plan, float* d_y, hipStream_t s) {
 }
 
 hipError_t launch_reduce(const TiledPlan& plan, float* d_y, hipStream_t s) {
-    if (reduce_block() == 512) {
-        return plan.lane_entries == 2 ? launch_reduce_as<512, 2, 4>(plan, d_y, s) : launch_reduce_as<512, 4, 4>(plan, d_y, s);
+    switch (plan.lane_entries) {
+        case 2:  return launch_reduce_as<1024, 2, 4>(plan, d_y, s);
+        case 4:  return launch_reduce_as<1024, 4, 2>(plan, d_y, s);
+        default: return launch_reduce_as<1024, 8, 1>(plan, d_y, s);
     }
-    return plan.lane_entries == 2 ? launch_reduce_as<1024, 2, 4>(plan, d_y, s) : launch_reduce_as<1024, 4, 2>(plan, d_y, s);
 }
 
 template <int BLOCK, int E, int kRuns>
@@ -1139,8 +1144,11 @@ hipError_t launch_pagerank_reduce(const TiledPlan& plan, int row_offset, int n_g
 #define SPMV_PR_REDUCE(BLOCK, E, RUNS) \
     launch_pagerank_reduce_as<BLOCK, E, RUNS>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state, \
                                               d_block_partials, push, s)
-    if (reduce_block() == 512) return plan.lane_entries == 2 ? SPMV_PR_REDUCE(512, 2, 4) : SPMV_PR_REDUCE(512, 4, 4);
-    return plan.lane_entries == 2 ? SPMV_PR_REDUCE(1024, 2, 4) : SPMV_PR_REDUCE(1024, 4, 2);
+    switch (plan.lane_entries) {
+        case 2:  return SPMV_PR_REDUCE(1024, 2, 4);
+        case 4:  return SPMV_PR_REDUCE(1024, 4, 2);
+        default: return SPMV_PR_REDUCE(1024, 8, 1);
+    }
 #undef SPMV_PR_REDUCE
 }
 
@@ -1409,12 +1417,16 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         return fail(err);
     };
     if (e != hipSuccess) return fail_with_strip(e);
-    {   // slots a lane takes per phase-2 load: 4 (16-byte loads) unless the runs are short
-        const long long mean_run = plan->nnz / std::max<long long>(cells, 1);
-        plan->lane_entries = mean_run <= 160 ? 2 : 4;
+    {   // Slots a lane takes per phase-2 pass (a wavefront's pass covers 64 of them from each run): 2, 4 or 8.
+        // Measured on C5 (mean run 258 slots): 205 / 207 / 208 us — phase 2 does not care (the LDS adds,
+        // 160 M ds_add_f64 = ~130 us of LDS pipe, and the 0.85 GB of loads, ~155 us, share the time; neither
+        // the pass count nor the instruction count moved it), so the choice only avoids mostly-empty passes.
+        const double mean_run = static_cast<double>(plan->nnz) / std::max<long long>(cells, 1);
+        const double typical = mean_run + 2.0 * std::sqrt(mean_run);
+        plan->lane_entries = typical <= 128 ? 2 : (typical <= 512 ? 4 : 8);
         if (const char* env = std::getenv("SPMV_TILED_LANE_ENTRIES")) {
             const int v = std::atoi(env);
-            if (v == 2 || v == 4) plan->lane_entries = v;
+            if (v == 2 || v == 4 || v == 8) plan->lane_entries = v;
         }
     }
 

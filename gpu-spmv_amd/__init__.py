@@ -198,6 +198,8 @@ _SIGNATURES = {
     "spmv_c_pagerank": (c_int, [POINTER(CSRMatrix), POINTER(PageRankConfig), POINTER(_PageRankResultC)]),
     "spmv_c_pagerank_free": (None, [POINTER(_PageRankResultC)]),
     "spmv_c_pagerank_top_k": (None, [POINTER(_PageRankResultC), c_int, c_int, POINTER(TopKNode)]),
+    "spmv_c_pagerank_multi_gpu": (c_int, [POINTER(CSRMatrix), POINTER(PageRankConfig), c_int, POINTER(_PageRankResultC)]),
+    "spmv_c_pagerank_shard_bounds": (c_int, [POINTER(c_int32), c_int, c_int, POINTER(c_int32)]),
     "spmv_c_pr_shard_create": (c_void_p, [POINTER(CSRMatrix), c_int, c_int, c_void_p]),
     "spmv_c_pr_shard_destroy": (None, [c_void_p]),
     "spmv_c_pr_reset": (c_int, [c_void_p, c_float, c_void_p]),
@@ -683,6 +685,18 @@ def pagerank(adj_matrix, config=None) -> PageRankResult:
         ranks = np.ctypeslib.as_array(raw.ranks, shape=(n,))
         import weakref
         weakref.finalize(ranks, lambda held=raw: lib().spmv_c_pagerank_free(byref(held)))
+    return PageRankResult(ranks, raw.iterations, float(raw.final_residual), bool(raw.converged))
+
+
+def pagerank_multi_gpu(adj_matrix, config=None, num_gpus=1) -> PageRankResult:
+    """include/spmv/pagerank.h extension: the row-sharded single-process RCCL loop over `num_gpus` devices."""
+    raw = _PageRankResultC()
+    lib().spmv_c_pagerank_multi_gpu(adj_matrix, byref(config) if config is not None else None, num_gpus, byref(raw))
+    if not raw.ranks:
+        return PageRankResult(None, 0, 0.0, False)
+    n = adj_matrix.contents.num_rows
+    ranks = np.ctypeslib.as_array(raw.ranks, shape=(n,)).copy()
+    lib().spmv_c_pagerank_free(byref(raw))
     return PageRankResult(ranks, raw.iterations, float(raw.final_residual), bool(raw.converged))
 
 

@@ -10,6 +10,7 @@
 
 #include <cstddef>
 #include <cstring>
+#include <vector>
 #include <new>
 
 using namespace spmv;
@@ -364,6 +365,25 @@ int spmv_c_pagerank(const spmv_c_csr* adj, const spmv_c_pagerank_config* config,
     out->final_residual = r.final_residual;
     out->converged = r.converged ? 1 : 0;
     return adj ? 0 : kInvalidArgument;
+}
+
+int spmv_c_pagerank_multi_gpu(const spmv_c_csr* adj, const spmv_c_pagerank_config* config, int num_gpus,
+                              spmv_c_pagerank_result* out) {
+    if (!out) return kInvalidArgument;
+    const PageRankResult r = pagerank_multi_gpu(cxx(adj), reinterpret_cast<const PageRankConfig*>(config), num_gpus);
+    std::memset(out, 0, sizeof(*out));
+    out->ranks = r.ranks;
+    out->iterations = r.iterations;
+    out->final_residual = r.final_residual;
+    out->converged = r.converged ? 1 : 0;
+    return adj ? 0 : kInvalidArgument;
+}
+
+int spmv_c_pagerank_shard_bounds(const int32_t* row_ptrs, int num_rows, int num_shards, int32_t* bounds) {
+    if (!row_ptrs || !bounds || num_rows < 0 || num_shards < 1) return kInvalidArgument;
+    const std::vector<int> b = pagerank_shard_bounds(row_ptrs, num_rows, num_shards);
+    std::copy(b.begin(), b.end(), bounds);
+    return 0;
 }
 
 void spmv_c_pagerank_free(spmv_c_pagerank_result* result) {

@@ -557,6 +557,14 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     const PageRankConfig fallback;
     if (!config) config = &fallback;
 
+    // extension: SPMV_NUM_GPUS=N shards the call over N devices (include/spmv/pagerank.h)
+    if (const char* env = std::getenv("SPMV_NUM_GPUS")) {
+        const int gpus = std::atoi(env);
+        if (gpus > 1 && adj->num_rows > 0 && adj->row_ptrs && (adj->nnz == 0 || (adj->col_indices && adj->values))) {
+            return pagerank_multi_gpu(adj, config, gpus);
+        }
+    }
+
     const int n = adj->num_rows;
     if (static_cast<size_t>(std::max(n, 0)) >= ResultPool::kMinPooled) result.ranks = result_pool().take(static_cast<size_t>(n));
     const bool pinned_result = result.ranks != nullptr;

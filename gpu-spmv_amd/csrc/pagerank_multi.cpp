@@ -1,0 +1,340 @@
+// pagerank_multi.cpp — row-sharded multi-GPU PageRank in ONE process, behind the reference's API.
+//
+// The reference has no multi-GPU code; its host loop is src/pagerank.cu:50-153 and its
+// public entry point include/spmv/pagerank.h:29-43.  pagerank_multi_gpu() keeps that entry point's
+// contract (same config, same result struct, result released by pagerank_free) and shards the CSR row
+// range over `num_gpus` devices:
+//
+//   * boundaries by binary search on row_ptrs for equal nnz (a power-law graph does not leave one device
+//     with most of the entries);
+//   * device p owns rows [bounds[p], bounds[p + 1]) and a full-length rank vector in the padded layout of
+//     csrc/pagerank.hip's shard engine (slice stride = longest block + 4 floats; the 16-byte tail of every
+//     slice carries that device's two partial sums as doubles);
+//   * per iteration, per device: the fused step kernels (direct vector-CSR or the LDS-tiled engine, the
+//     same pr_step the single-GPU loop runs), then ONE in-place ncclAllGather of `stride` floats per device
+//     over xGMI (RCCL, single-process ncclCommInitAll, one stream per device, grouped calls), then
+//     pr_commit_gathered folds the P partial pairs in device order — identical state on every device, no
+//     separate all-reduce;
+//   * the host runs one step ahead of the convergence check (device-side `done` flag, pinned mirror), as the
+//     single-GPU loop does; RCCL failures surface as an empty result, never as a hang on our side.
+//
+// librccl is loaded lazily (dlopen) so that the library itself has no hard dependency on it; with
+// num_gpus == 1 the exchange degenerates to nothing and RCCL is not touched unless
+// SPMV_MULTI_GPU_FORCE_RCCL is set (the single-GPU test box exercises the collective path that way).
+#include "internal.h"
+#include "pagerank_engine.h"
+#include "tiled.h"
+#include "spmv/pagerank.h"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace spmv {
+
+namespace {
+
+constexpr int kTail = 4;        // floats appended to every slice: two doubles of partial sums
+
+struct Rccl {
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    bool ok = false;
+};
+
+const Rccl& rccl() {
+    static Rccl api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+        api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(lib, "ncclAllGather"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        api.ok = api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd;
+    });
+    return api;
+}
+
+// what one device holds
+struct DeviceShard {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int* d_row_ptrs = nullptr;
+    int* d_cols = nullptr;
+    float* d_vals = nullptr;
+    unsigned char* d_mask = nullptr;
+    float* r[2] = {nullptr, nullptr};
+    CSRMatrix header;               // wraps the three arrays (side-table key for the tiled plan)
+    detail::PrShard shard;
+    ncclComm_t comm = nullptr;
+    bool have_header = false;
+};
+
+void release(std::vector<DeviceShard>& shards, const Rccl* api) {
+    for (DeviceShard& d : shards) {
+        if (hipSetDevice(d.device) != hipSuccess) continue;
+        if (d.stream) (void)hipStreamSynchronize(d.stream);
+        if (d.comm && api) (void)api->CommDestroy(d.comm);
+        if (d.have_header) detail::aux_drop(d.header.d_row_ptrs);          // the shard's tiled plan, if any
+        for (void* p : {static_cast<void*>(d.d_row_ptrs), static_cast<void*>(d.d_cols), static_cast<void*>(d.d_vals),
+                        static_cast<void*>(d.d_mask), static_cast<void*>(d.r[0]), static_cast<void*>(d.r[1]),
+                        static_cast<void*>(d.shard.d_state), static_cast<void*>(d.shard.d_block_partials)}) {
+            if (p) (void)hipFree(p);
+        }
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+    }
+    shards.clear();
+}
+
+} // namespace
+
+std::vector<int> pagerank_shard_bounds(const int* row_ptrs, int num_rows, int num_shards) {
+    std::vector<int> bounds(static_cast<size_t>(num_shards) + 1, 0);
+    bounds[num_shards] = num_rows;
+    const long long nnz = row_ptrs[num_rows];
+    for (int p = 1; p < num_shards; ++p) {
+        const long long target = (nnz * p + num_shards / 2) / num_shards;
+        int at = static_cast<int>(std::lower_bound(row_ptrs, row_ptrs + num_rows + 1, target) - row_ptrs);
+        at = std::min(at, num_rows);
+        // the search lands on the first boundary at or past the target; the one before may be nearer
+        if (at > 0 && target - row_ptrs[at - 1] < row_ptrs[at] - target) --at;
+        bounds[p] = std::max(at, bounds[p - 1]);
+    }
+    return bounds;
+}
+
+PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* config, int num_gpus) {
+    PageRankResult result;
+    if (!adj) return result;
+    const PageRankConfig fallback;
+    if (!config) config = &fallback;
+    const int n = adj->num_rows;
+    if (n <= 0 || num_gpus < 1 || !adj->row_ptrs || (adj->nnz > 0 && (!adj->col_indices || !adj->values))) {
+        // the shards are cut from the HOST arrays (csr_from_dense / csr_deserialize / csr_from_gpu provide them)
+        return n <= 0 || num_gpus < 1 ? pagerank(adj, config) : result;
+    }
+    int available = 0;
+    if (hipGetDeviceCount(&available) != hipSuccess || available < num_gpus) {
+        (void)hipGetLastError();
+        return result;
+    }
+    int previous_device = 0;
+    (void)hipGetDevice(&previous_device);
+
+    const int P = num_gpus;
+    const bool force_rccl = std::getenv("SPMV_MULTI_GPU_FORCE_RCCL") != nullptr;
+    const bool exchange = P > 1 || force_rccl;
+    const Rccl* api = exchange ? &rccl() : nullptr;
+    if (api && !api->ok) {
+        std::fprintf(stderr, "spmv: librccl not available, pagerank_multi_gpu cannot exchange rank slices\n");
+        return result;
+    }
+
+    // ---- partition: equal nnz; padded layout of the rank vector
+    const std::vector<int> bounds = pagerank_shard_bounds(adj->row_ptrs, n, P);
+    int longest = 0;
+    for (int p = 0; p < P; ++p) longest = std::max(longest, bounds[p + 1] - bounds[p]);
+    if (longest % 2) ++longest;                                  // 8-byte aligned tails
+    const long long stride = longest + (exchange ? kTail : 0);
+    const long long padded = stride * P;
+    if (padded > 0x7fffffffLL) return result;
+    auto position = [&](int node) {                              // node -> index in the padded vector
+        const int owner = static_cast<int>(std::upper_bound(bounds.begin() + 1, bounds.end() - 1, node) - (bounds.begin() + 1));
+        return static_cast<int>(owner * stride + (node - bounds[owner]));
+    };
+
+    // dangling columns exactly as the reference's host scan (src/pagerank.cu:20-48), in padded positions
+    std::vector<unsigned char> mask(static_cast<size_t>(padded), 0);
+    unsigned long long num_dangling = 0;
+    {
+        std::vector<float> sums(static_cast<size_t>(adj->num_cols), 0.0f);
+        for (int r = 0; r < n; ++r) {
+            for (int j = adj->row_ptrs[r]; j < adj->row_ptrs[r + 1]; ++j) {
+                const int c = adj->col_indices[j];
+                if (c >= 0 && c < adj->num_cols) sums[c] += adj->values[j];
+            }
+        }
+        for (int c = 0; c < std::min(n, adj->num_cols); ++c) {
+            if (sums[c] == 0.0f) {
+                mask[position(c)] = 1;
+                ++num_dangling;
+            }
+        }
+    }
+    const float start = 1.0f / n;
+    detail::PrState first_state{};
+    for (unsigned long long k = 0; k < num_dangling; ++k) first_state.dangling_sum += start;
+    std::vector<float> start_vector(static_cast<size_t>(padded), 0.0f);
+    for (int p = 0; p < P; ++p) {
+        std::fill_n(start_vector.begin() + p * stride, bounds[p + 1] - bounds[p], start);
+    }
+
+    // ---- upload the shards
+    std::vector<DeviceShard> shards(P);
+    bool ok = true;
+    std::vector<int> local_cols;
+    for (int p = 0; p < P && ok; ++p) {
+        DeviceShard& d = shards[p];
+        d.device = p;
+        const int rows = bounds[p + 1] - bounds[p];
+        const int first = adj->row_ptrs[bounds[p]];
+        const int local_nnz = adj->row_ptrs[bounds[p + 1]] - first;
+        std::vector<int> local_ptrs(static_cast<size_t>(rows) + 1);
+        for (int r = 0; r <= rows; ++r) local_ptrs[r] = adj->row_ptrs[bounds[p] + r] - first;
+        local_cols.resize(static_cast<size_t>(std::max(local_nnz, 1)));
+        for (int j = 0; j < local_nnz; ++j) {
+            const int c = adj->col_indices[first + j];
+            local_cols[j] = c >= 0 && c < n ? position(c) : 0;   // node ids -> positions in the padded vector
+        }
+        ok = hipSetDevice(p) == hipSuccess
+          && hipStreamCreate(&d.stream) == hipSuccess
+          && hipMalloc(reinterpret_cast<void**>(&d.d_row_ptrs), (static_cast<size_t>(rows) + 1) * sizeof(int)) == hipSuccess
+          && hipMalloc(reinterpret_cast<void**>(&d.d_cols), static_cast<size_t>(std::max(local_nnz, 1)) * sizeof(int)) == hipSuccess
+          && hipMalloc(reinterpret_cast<void**>(&d.d_vals), static_cast<size_t>(std::max(local_nnz, 1)) * sizeof(float)) == hipSuccess
+          && hipMalloc(reinterpret_cast<void**>(&d.d_mask), static_cast<size_t>(padded)) == hipSuccess
+          && hipMalloc(reinterpret_cast<void**>(&d.r[0]), static_cast<size_t>(padded) * sizeof(float)) == hipSuccess
+          && hipMalloc(reinterpret_cast<void**>(&d.r[1]), static_cast<size_t>(padded) * sizeof(float)) == hipSuccess
+          && hipMemcpy(d.d_row_ptrs, local_ptrs.data(), local_ptrs.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess
+          && hipMemcpy(d.d_cols, local_cols.data(), static_cast<size_t>(local_nnz) * sizeof(int), hipMemcpyHostToDevice) == hipSuccess
+          && hipMemcpy(d.d_vals, adj->values + first, static_cast<size_t>(local_nnz) * sizeof(float), hipMemcpyHostToDevice) == hipSuccess
+          && hipMemcpy(d.d_mask, mask.data(), mask.size(), hipMemcpyHostToDevice) == hipSuccess
+          && hipMemcpy(d.r[0], start_vector.data(), start_vector.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess
+          && hipMemcpy(d.r[1], start_vector.data(), start_vector.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok) break;
+        std::memset(&d.header, 0, sizeof(d.header));
+        d.header.num_rows = rows;
+        d.header.num_cols = static_cast<int>(padded);
+        d.header.nnz = local_nnz;
+        d.header.d_row_ptrs = d.d_row_ptrs;
+        d.header.d_col_indices = d.d_cols;
+        d.header.d_values = d.d_vals;
+        d.have_header = true;
+        detail::PrShard& sh = d.shard;
+        sh.local_rows = rows;
+        sh.row_offset = static_cast<int>(p * stride);
+        sh.n_global = n;
+        sh.nnz = local_nnz;
+        sh.d_row_ptrs = d.d_row_ptrs;
+        sh.d_cols = d.d_cols;
+        sh.d_vals = d.d_vals;
+        sh.d_dangling = d.d_mask;
+        const int pairs = detail::pr_shard_prepare(&sh, detail::tiled_plan_for(&d.header, d.stream));
+        ok = hipMalloc(reinterpret_cast<void**>(&sh.d_state), sizeof(detail::PrState)) == hipSuccess
+          && hipMalloc(reinterpret_cast<void**>(&sh.d_block_partials), 2 * sizeof(double) * static_cast<size_t>(pairs)) == hipSuccess
+          && hipMemcpy(sh.d_state, &first_state, sizeof(first_state), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (ok && exchange) {
+        std::vector<int> devices(P);
+        std::vector<ncclComm_t> comms(P, nullptr);
+        for (int p = 0; p < P; ++p) devices[p] = p;
+        ok = api->CommInitAll(comms.data(), P, devices.data()) == ncclSuccess;
+        for (int p = 0; p < P; ++p) shards[p].comm = comms[p];
+    }
+
+    // ---- the loop: the host enqueues step k + 1 on every device before it looks at the outcome of step k
+    detail::PrState* pinned = nullptr;
+    hipEvent_t seen[2] = {nullptr, nullptr};
+    detail::PrState last_state{};
+    if (ok) {
+        ok = hipSetDevice(0) == hipSuccess
+          && hipHostMalloc(reinterpret_cast<void**>(&pinned), 2 * sizeof(detail::PrState)) == hipSuccess
+          && hipEventCreateWithFlags(&seen[0], hipEventDisableTiming) == hipSuccess
+          && hipEventCreateWithFlags(&seen[1], hipEventDisableTiming) == hipSuccess;
+    }
+    for (int iter = 0; ok && iter < config->max_iterations; ++iter) {
+        for (int p = 0; p < P && ok; ++p) {
+            DeviceShard& d = shards[p];
+            const float* r_old = d.r[iter & 1];
+            float* r_new = d.r[(iter + 1) & 1];
+            ok = hipSetDevice(p) == hipSuccess
+              && detail::pr_step(d.shard, r_old, r_new, config->damping_factor, detail::PushTargets{}, d.stream) == hipSuccess;
+            if (!ok) break;
+            if (exchange) {      // the two partial sums go into the tail of this device's own slice
+                double* tail = reinterpret_cast<double*>(r_new + p * stride + longest);
+                ok = detail::pr_reduce(d.shard, tail, d.stream) == hipSuccess;
+            } else {
+                ok = detail::pr_reduce_commit(d.shard, config->tolerance, d.stream) == hipSuccess;
+            }
+        }
+        if (ok && exchange) {
+            ok = api->GroupStart() == ncclSuccess;
+            for (int p = 0; p < P && ok; ++p) {
+                float* r_new = shards[p].r[(iter + 1) & 1];
+                ok = api->AllGather(r_new + p * stride, r_new, static_cast<size_t>(stride), ncclFloat, shards[p].comm,
+                                    shards[p].stream) == ncclSuccess;
+            }
+            ok = api->GroupEnd() == ncclSuccess && ok;
+            for (int p = 0; p < P && ok; ++p) {
+                ok = hipSetDevice(p) == hipSuccess
+                  && detail::pr_commit_gathered(shards[p].shard, shards[p].r[(iter + 1) & 1], P, stride, longest,
+                                                config->tolerance, shards[p].stream) == hipSuccess;
+            }
+        }
+        if (!ok) break;
+        ok = hipSetDevice(0) == hipSuccess
+          && hipMemcpyAsync(&pinned[iter & 1], shards[0].shard.d_state, sizeof(detail::PrState), hipMemcpyDeviceToHost,
+                            shards[0].stream) == hipSuccess
+          && hipEventRecord(seen[iter & 1], shards[0].stream) == hipSuccess;
+        if (ok && iter >= 1) {
+            ok = hipEventSynchronize(seen[(iter - 1) & 1]) == hipSuccess;
+            if (ok && pinned[(iter - 1) & 1].done) break;
+        }
+    }
+    for (int p = 0; p < P && ok; ++p) {
+        ok = hipSetDevice(p) == hipSuccess && hipStreamSynchronize(shards[p].stream) == hipSuccess;
+    }
+    if (ok) {
+        ok = hipSetDevice(0) == hipSuccess
+          && hipMemcpy(&last_state, shards[0].shard.d_state, sizeof(last_state), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+
+    // ---- result: the last written vector, slices compacted, r /= sum(r) accumulated in double
+    if (ok) {
+        result.iterations = last_state.iterations;
+        result.final_residual = last_state.final_residual;
+        result.converged = last_state.converged != 0;
+        result.ranks = new float[n];
+        const float* last = shards[0].r[last_state.iterations & 1];
+        if (exchange) {
+            for (int p = 0; p < P && ok; ++p) {
+                ok = hipMemcpy(result.ranks + bounds[p], last + p * stride, static_cast<size_t>(bounds[p + 1] - bounds[p]) * sizeof(float),
+                               hipMemcpyDeviceToHost) == hipSuccess;
+            }
+        } else {
+            ok = hipMemcpy(result.ranks, last, static_cast<size_t>(n) * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        if (ok) {
+            double total = 0.0;
+            for (int i = 0; i < n; ++i) total += result.ranks[i];
+            const float divisor = static_cast<float>(total);
+            if (divisor > 0.0f) for (int i = 0; i < n; ++i) result.ranks[i] /= divisor;
+        } else {
+            delete[] result.ranks;
+            result = PageRankResult();
+        }
+    }
+    if (pinned) (void)hipHostFree(pinned);
+    for (hipEvent_t e : seen) if (e) (void)hipEventDestroy(e);
+    release(shards, api);
+    (void)hipSetDevice(previous_device);
+    (void)hipGetLastError();
+    return result;
+}
+
+} // namespace spmv

@@ -9,6 +9,8 @@
 
 #include "csr_matrix.h"
 
+#include <vector>
+
 namespace spmv {
 
 struct PageRankConfig {
@@ -29,7 +31,19 @@ struct PageRankResult {
 };
 
 // adj_matrix: column-normalised adjacency in CSR (row i = in-links of node i).
+// Extension: with SPMV_NUM_GPUS=N (N > 1) in the environment and host arrays present, the call runs
+// pagerank_multi_gpu(adj_matrix, config, N) instead; unset, behaviour is the reference's single-device one.
 PageRankResult pagerank(const CSRMatrix* adj_matrix, const PageRankConfig* config = nullptr);
+
+// Extension (the reference is single-GPU): the same iteration with the CSR rows sharded
+// over `num_gpus` devices of this process — contiguous row blocks cut for equal nnz (binary search on
+// row_ptrs), every device a full-length rank vector, ONE RCCL all-gather of the new slices per iteration
+// (single-process ncclCommInitAll, one stream per device).  Shards are cut from the HOST arrays; the matrix
+// need not be resident on any device.  Same result contract as pagerank(): ranks released by pagerank_free;
+// an empty result (ranks == nullptr) when fewer than num_gpus devices or no RCCL are available.
+PageRankResult pagerank_multi_gpu(const CSRMatrix* adj_matrix, const PageRankConfig* config, int num_gpus);
+// the row boundaries it cuts (num_shards + 1 ascending row indices, bounds[0] = 0, bounds[num_shards] = num_rows)
+std::vector<int> pagerank_shard_bounds(const int* row_ptrs, int num_rows, int num_shards);
 
 void pagerank_free(PageRankResult* result);
 

@@ -221,6 +221,15 @@ float spmv_c_get_gpu_peak_bandwidth(void);
 int spmv_c_pagerank(const spmv_c_csr* adj, const spmv_c_pagerank_config* config,
                     spmv_c_pagerank_result* out);
 void spmv_c_pagerank_free(spmv_c_pagerank_result* result);
+/* extension (the reference's pagerank(), include/spmv/pagerank.h:29-31, is single-device): the same call
+ * with the CSR rows sharded over num_gpus devices of this process, equal-nnz row blocks, one RCCL all-gather
+ * of the rank slices per iteration.  Needs the matrix's HOST arrays.  out->ranks == NULL when fewer than
+ * num_gpus devices or no librccl are available.  Returns 0, or -8 for null arguments. */
+int spmv_c_pagerank_multi_gpu(const spmv_c_csr* adj, const spmv_c_pagerank_config* config, int num_gpus,
+                              spmv_c_pagerank_result* out);
+/* extension: the row boundaries pagerank_multi_gpu uses — bounds[num_shards + 1], binary search on the host
+ * row_ptrs for equal nnz */
+int spmv_c_pagerank_shard_bounds(const int32_t* row_ptrs, int num_rows, int num_shards, int32_t* bounds);
 void spmv_c_pagerank_top_k(const spmv_c_pagerank_result* result, int num_nodes, int k,
                            spmv_c_topk_node* top_k);
 

@@ -37,3 +37,14 @@ def test_reference_gtest_cases_restated_in_cpp(gpu):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "all reference cases passed" in out.stdout, out.stdout[-4000:] + out.stderr[-2000:]
     assert out.stdout.count("[  OK  ]") == 48, out.stdout[-2000:]
+
+
+def test_native_multi_gpu_pagerank_entry_point(gpu):
+    """tests/cpp/multi_gpu_pagerank.cpp: pagerank_multi_gpu(adj, config, 1) — the single-process RCCL host loop
+    behind the reference's API (include/spmv/pagerank.h extension) — equals pagerank() on a uniform and on a
+    power-law graph, both without and with the RCCL all-gather in the loop (one device: SPMV_MULTI_GPU_FORCE_RCCL),
+    and the equal-nnz shard boundaries are right."""
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "multi_gpu_pagerank")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe, "run", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "all checks passed (bounds + run)" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]

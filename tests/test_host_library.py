@@ -323,3 +323,21 @@ def test_shard_engine_rejects_bad_arguments_without_touching_a_gpu(spmv):
     assert not lib.spmv_c_pr_shard_create(A, 1, 4, mask)                       # rows would run past the vector
     assert not lib.spmv_c_pr_shard_create(A, 0, 4, mask)                       # rows but no device arrays
     spmv.csr_destroy(A)
+
+
+def test_native_multi_gpu_shard_bounds_on_the_host(spmv):
+    """tests/cpp/multi_gpu_pagerank (bounds mode, no GPU): pagerank_shard_bounds — binary search on row_ptrs for
+    equal nnz, SURVEY.md §8(e) — through the C++ API; and the same through the C ABI."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "multi_gpu_pagerank")
+    if not os.path.exists(exe):
+        pytest.skip("tests/cpp/bin not built (run __graft_entry__.build())")
+    out = subprocess.run([exe, "bounds"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "all checks passed (bounds only)" in out.stdout, out.stdout + out.stderr
+    import ctypes
+    rp = np.array([0, 10, 10, 11, 12, 40, 41], dtype=np.int32)
+    bounds = np.zeros(3, dtype=np.int32)
+    lib = spmv.lib()
+    assert lib.spmv_c_pagerank_shard_bounds(rp.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 6, 2,
+                                            bounds.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))) == 0
+    assert bounds.tolist() == [0, 4, 6]

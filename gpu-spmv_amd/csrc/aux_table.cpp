@@ -6,6 +6,10 @@
 #include "internal.h"
 #include "tiled.h"
 
+#include <dlfcn.h>
+
+#include <cstdlib>
+
 #include <mutex>
 #include <unordered_map>
 
@@ -34,6 +38,44 @@ void release(CsrAux* a) {
 }
 
 } // namespace
+
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+const Roctx& roctx() {
+    static Roctx api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the marker library a profiler already brought into the process, or — on request (SPMV_ROCTX=1, e.g.
+        // under `rocprofv3 --marker-trace`) — loaded here; never loaded into an unprofiled process
+        void* lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!lib && std::getenv("SPMV_ROCTX")) {
+            lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!lib) return;
+        api.push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+        api.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!api.push || !api.pop) api = Roctx();
+    });
+    return api;
+}
+} // namespace
+
+TraceRange::TraceRange(const char* name) : open_(false) {
+    const Roctx& api = roctx();
+    if (api.push) {
+        (void)api.push(name);
+        open_ = true;
+    }
+}
+
+TraceRange::~TraceRange() {
+    if (open_) (void)roctx().pop();
+}
 
 void PrWorkspace::release() {
     for (void* p : {static_cast<void*>(r[0]), static_cast<void*>(r[1]), static_cast<void*>(mask), static_cast<void*>(partials),
@@ -100,6 +142,7 @@ const TiledPlan* tiled_plan_for(const CSRMatrix* A, hipStream_t s) {
         aux->tiled_failed = false;
     }
     if (!aux->tiled && !aux->tiled_failed) {
+        const TraceRange range("spmv:tiled_plan_build");
         if (tiled_build(A, &aux->tiled, s) != hipSuccess) {
             (void)hipGetLastError();
             aux->tiled = nullptr;

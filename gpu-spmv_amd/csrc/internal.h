@@ -107,6 +107,18 @@ EventPair& thread_events();
 
 hipStream_t current_stream();
 
+// roctx range around a host-side phase (plan build, dispatch, PageRank step): shows up under
+// `rocprofv3 --marker-trace`, costs two indirect calls when a profiler has loaded the roctx library and
+// nothing measurable otherwise (the library is looked up once, lazily; no link-time dependency).
+struct TraceRange {
+    explicit TraceRange(const char* name);
+    ~TraceRange();
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+private:
+    bool open_;
+};
+
 } // namespace detail
 } // namespace spmv
 

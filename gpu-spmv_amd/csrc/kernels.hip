@@ -468,12 +468,11 @@ hipError_t launch_vector(const CSRMatrix* A, const float* d_x, float* d_y, hipSt
 template <int LANES>
 hipError_t launch_vector_ldsx(const CSRMatrix* A, const float* d_x, float* d_y, int grid, hipStream_t s) {
     const size_t lds = (static_cast<size_t>(A->num_cols) * sizeof(float) + 15) & ~size_t(15);
-    static bool raised = false;       // > 64 KiB of dynamic LDS needs the limit raised once per kernel
-    if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_vector_ldsx_kernel<LANES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised = true;
-    }
+    // > 64 KiB of dynamic LDS needs the limit raised; the attribute is per DEVICE and cheap to set, so it is
+    // set on every launch (no process-wide flag to go stale after hipSetDevice, nothing shared between threads)
+    const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_vector_ldsx_kernel<LANES>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (raised != hipSuccess) return raised;
     csr_vector_ldsx_kernel<LANES><<<grid, 1024, lds, s>>>(A->num_rows, A->num_cols, A->nnz, A->d_row_ptrs,
                                                           A->d_col_indices, A->d_values, d_x, d_y);
     return hipGetLastError();

@@ -584,6 +584,7 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
         return result;
     }
 
+    const detail::TraceRange range("spmv:pagerank");
     hipStream_t stream = detail::current_stream();
     using detail::PrState;
     const Trace trace("pagerank");
@@ -687,6 +688,7 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
             if (plan) (void)detail::pr_shard_prepare(&shard, plan);
             trace.mark("plan build (after direct steps)");
         }
+        const detail::TraceRange step_range("spmv:pagerank_step");
         const float* r_old = bufs[iter & 1];
         float* r_new = bufs[(iter + 1) & 1];
         ok = ok && detail::pr_step(shard, r_old, r_new, config->damping_factor, detail::PushTargets{}, stream) == hipSuccess

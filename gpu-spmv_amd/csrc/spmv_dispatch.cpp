@@ -169,6 +169,7 @@ SpMVResult spmv_csr(const CSRMatrix* A, const float* d_x, float* d_y,
         return result;
     }
 
+    const detail::TraceRange range("spmv:spmv_csr");
     hipStream_t stream = detail::current_stream();
     // one-time auxiliary data (the LDS-tiled plan, the merge-path tile table) is built BEFORE the start
     // event: elapsed_ms / gflops / bandwidth_gb_s of the first call then mean what they mean on every later one
@@ -217,6 +218,7 @@ SpMVResult spmv_ell(const ELLMatrix* A, const float* d_x, float* d_y,
         return result;
     }
 
+    const detail::TraceRange range("spmv:spmv_ell");
     hipStream_t stream = detail::current_stream();
     if (config->use_texture && A->max_nnz_per_row > 0) (void)detail::tiled_plan_for(A, stream);   // outside the timed region
     result.error_code = detail::timed(stream, &result.elapsed_ms, [&] {

@@ -179,7 +179,9 @@ const TiledPlan* tiled_plan_for(const ELLMatrix* A, hipStream_t s) {
     if (!A || !A->d_col_indices || !A->d_values || !tiled_eligible(A)) return nullptr;
     std::lock_guard<std::mutex> building(g_build_lock);
     EllAux* aux = ell_aux_lookup(A->d_col_indices, true);
-    if (aux->tiled && (aux->tiled->num_rows != A->num_rows || aux->tiled->num_cols != A->num_cols)) {
+    if (aux->tiled && (aux->tiled->num_rows != A->num_rows || aux->tiled->num_cols != A->num_cols ||
+                       aux->tiled->csr_nnz != static_cast<long long>(A->num_rows) * A->max_nnz_per_row ||
+                       aux->tiled->csr_vals != A->d_values)) {
         tiled_free(aux->tiled);
         aux->tiled = nullptr;
         aux->tiled_failed = false;

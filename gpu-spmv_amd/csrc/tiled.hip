@@ -1376,6 +1376,8 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         plan->csr_row_ptrs = A->d_row_ptrs;
         plan->csr_cols = A->d_col_indices;
         plan->csr_vals = A->d_values;
+    } else {
+        plan->csr_vals = src.ell->d_values;       // identity of the slabs the plan was built from (aux_table.cpp)
     }
     choose_shape(src.rows, src.cols, src.nnz, &plan->strip_cols, &plan->tile_rows);
     plan->num_strips = (src.cols + plan->strip_cols - 1) / plan->strip_cols;

@@ -235,12 +235,26 @@ class HipEngine:
         return out.iterations, float(out.final_residual), bool(out.converged), bool(out.done)
 
     def close(self):
+        """Destroys the shard and the matrix handle — and with it the side table (tiled plan, merge tables)
+        keyed by the device arrays: torch's caching allocator may hand the same addresses to the next matrix."""
         if self._shard:
             lib().spmv_c_pr_shard_destroy(self._shard)
             self._shard = None
         if self._A is not None:
             csr_destroy(self._A)
             self._A = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:           # interpreter teardown: the library may be gone
+            pass
 
 
 class ShardedPageRank:

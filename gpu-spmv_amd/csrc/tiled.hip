@@ -103,8 +103,8 @@ constexpr int kBuildBlock = 1024;           // threads of a builder workgroup
 constexpr int kBuildRowCache = 1024;        // row offsets of the batch kept in LDS for the entry -> row search
 constexpr int kBuildLdsSmall = 70 * 1024;   // dynamic LDS of a builder workgroup (two per CU, next to 8 KiB static) ...
 constexpr int kBuildLdsLarge = 148 * 1024;  // ... or one per CU when the strips are many
-constexpr int kBuildBinWords = 5;           // LDS ints per strip: start, cursor, escapes, first|last, spare
-constexpr int kBuildEntryBytes = 14;        // LDS bytes per entry: key 4, value 4, bin 2, rank 2, markers|delta 2
+constexpr int kBuildBinWords = 4;           // LDS ints per strip: start, cursor, markers, first|last
+constexpr int kBuildEntryBytes = 13;        // LDS bytes per entry: key 4, source index 4, bin 2, row mark 2, markers 1
 constexpr int kMaxBuildStrips = 3072;
 
 // where the entries come from.  offset(row) = index of the row's first entry in a virtual row-major
@@ -187,23 +187,33 @@ void batch_rows_kernel(Src src, BuildShape sh, const int* __restrict__ tile_batc
     if (t == sh.num_tiles - 1 && threadIdx.x == 0) batch_row[tile_batch[sh.num_tiles]] = sh.num_rows;
 }
 
-// per (batch, strip) group: what pass 0 learns / what pass 1 needs (same 8-byte slot)
-struct GroupCount { unsigned short count, first, last, escapes; };      // escapes: inside the group only
-struct GroupPlace { unsigned int rel; unsigned short prev_last, unused; };   // rel: offset inside the cell
+// per (batch, strip) group: what the ranking pass learns / what the placing pass needs (same 8-byte slot)
+struct GroupCount { unsigned short count, first, last, escapes; };      // escapes: markers in front of the non-first slots
+struct GroupPlace { unsigned int rel; unsigned short prev_last, lead; };   // rel: offset inside the cell; lead: markers
+                                                                         // in front of the group's first slot
 static_assert(sizeof(GroupCount) == 8 && sizeof(GroupPlace) == 8, "group records share storage");
 
-// One batch (consecutive rows of one tile, at most `capacity` short-row entries): bin the entries by strip
-// in LDS, rank every entry inside its bin by (row, column), derive the row deltas and the skip markers
-// they need.  PASS 0 reports each bin's size; PASS 1 writes the slots to their cells.
-// Dynamic LDS: kBuildBinWords ints per strip, then per entry key u32, value f32, bin u16, rank u16, markers|delta u16.
-template <typename Src, int PASS>
-__global__ __launch_bounds__(kBuildBlock)
-void batch_sort_kernel(Src src, BuildShape sh, int num_batches, int capacity,
+// Per-entry record the ranking pass leaves for the placing pass (indexed like the source entries):
+//   the first slot of its group : 1 << 31 | row inside the tile   (its delta and markers depend on the cell's
+//                                                                   earlier batches: cell_place_kernel settles them)
+//   any other slot              : p << 16 | markers << 8 | delta   (p = slots of the group in front of it, its own
+//                                                                   markers included, the group's lead excluded)
+//   an entry of a long row      : kMetaSkip
+constexpr unsigned int kMetaFirst = 1u << 31;
+constexpr unsigned int kMetaSkip = 0xFFFFFFFFu;
+constexpr int kBuildPerThread = 8;                     // entries a builder thread keeps in registers
+constexpr int kBuildMaxCapacity = kBuildBlock * kBuildPerThread;
+
+// One batch (consecutive rows of one tile, at most `capacity` short-row entries): bin the entries by strip in
+// LDS, rank every entry inside its bin by (row, column), derive the row deltas and the skip markers they need;
+// report every bin's size and leave the per-entry records.  Dynamic LDS: kBuildBinWords ints per strip, then
+// per entry key u32, source index u32, bin u16, row mark u16, markers u8.
+template <typename Src>
+__global__ __launch_bounds__(kBuildBlock, 8)          // two workgroups per CU: at most 64 registers
+void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
                        const int* __restrict__ batch_row, const int* __restrict__ batch_tile,
-                       uint2* __restrict__ groups,                 // [batches * strips] GroupCount / GroupPlace
-                       const int* __restrict__ offs,               // PASS 1: cell begins, strip-major
-                       float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
-                       unsigned char* __restrict__ a_drow,
+                       uint2* __restrict__ groups,                 // [batches * strips] GroupCount
+                       unsigned int* __restrict__ meta,            // [source entries]
                        int* __restrict__ long_rows, int* __restrict__ num_long) {
     extern __shared__ int build_lds[];
     __shared__ int s_partial[kBuildBlock];
@@ -214,13 +224,13 @@ void batch_sort_kernel(Src src, BuildShape sh, int num_batches, int capacity,
     const int S = sh.num_strips;
     int* bin_start = build_lds;                 // [S] first slot of the bin (after the scan)
     int* bin_cursor = build_lds + S;            // [S] histogram, then fill cursor (= bin end once filled)
-    int* bin_escapes = build_lds + 2 * S;       // [S] skip markers needed inside the bin
+    int* bin_escapes = build_lds + 2 * S;       // [S] skip markers needed in front of the bin's non-first slots
     int* bin_ends = build_lds + 3 * S;          // [S] first lrow << 16 | last lrow
     unsigned int* keys = reinterpret_cast<unsigned int*>(build_lds + kBuildBinWords * S);    // lrow << 16 | lcol
-    float* vals = reinterpret_cast<float*>(keys + capacity);
-    unsigned short* bin_of = reinterpret_cast<unsigned short*>(vals + capacity);
-    unsigned short* rank_of = bin_of + capacity;          // PASS 1: rank inside the bin
-    unsigned short* need_delta = rank_of + capacity;      // PASS 1: markers in front << 8 | row delta
+    unsigned int* source = keys + capacity;     // index of the slot's entry, relative to the batch's first entry
+    unsigned short* bin_of = reinterpret_cast<unsigned short*>(source + capacity);
+    unsigned short* row_mark = bin_of + capacity;          // entry index -> row (relative), after a max-scan
+    unsigned char* markers = reinterpret_cast<unsigned char*>(row_mark + capacity);
 
     const int tile = batch_tile[batch];
     const int row0 = batch_row[batch];
@@ -229,6 +239,11 @@ void batch_sort_kernel(Src src, BuildShape sh, int num_batches, int capacity,
     const int row1 = batch + 1 < num_batches && batch_tile[batch + 1] == tile ? batch_row[batch + 1]
                                                                                 : static_cast<int>(tile_end);
     const int tile_first = tile * sh.tile_rows;
+    const long long entry0 = src.offset(row0), entry1 = src.offset(row1);
+    // FAST: the batch's whole entry range fits the LDS arrays (always, unless long rows sit inside it): every
+    // thread keeps its entries' columns and rows in registers between the phases, rows come from a scan
+    const bool fast = entry1 - entry0 <= capacity;
+    const int span = fast ? static_cast<int>(entry1 - entry0) : 0;
 
     for (int i = threadIdx.x; i < S; i += kBuildBlock) {
         bin_cursor[i] = 0;
@@ -236,12 +251,42 @@ void batch_sort_kernel(Src src, BuildShape sh, int num_batches, int capacity,
         bin_ends[i] = 0;
     }
     if (threadIdx.x == 0) s_overflow = 0;
-    // entry -> row: binary search over the batch's row offsets, staged in LDS when the batch has few enough rows
-    const bool rows_cached = Src::kSearchRows && row1 - row0 <= kBuildRowCache;
+    const bool rows_cached = Src::kSearchRows && !fast && row1 - row0 <= kBuildRowCache;
     if (rows_cached) {
         for (int r = row0 + threadIdx.x; r <= row1; r += kBuildBlock) s_row_cache[r - row0] = static_cast<int>(src.offset(r));
     }
+    if (fast && Src::kSearchRows) {
+        for (int i = threadIdx.x; i < span; i += kBuildBlock) row_mark[i] = 0;
+    }
     __syncthreads();
+    if (fast && Src::kSearchRows) {
+        // every non-empty row marks its first entry; an inclusive max-scan then gives every entry its row
+        for (int r = row0 + threadIdx.x; r < row1; r += kBuildBlock) {
+            const long long b = src.offset(r);
+            if (src.offset(r + 1) > b) row_mark[b - entry0] = static_cast<unsigned short>(r - row0);
+        }
+        __syncthreads();
+        const int per = (span + kBuildBlock - 1) / kBuildBlock;
+        const int lo = min(span, per * static_cast<int>(threadIdx.x)), hi = min(span, lo + per);
+        int best = 0;
+        for (int i = lo; i < hi; ++i) best = max(best, static_cast<int>(row_mark[i]));
+        s_partial[threadIdx.x] = best;
+        __syncthreads();
+        for (int off = 1; off < kBuildBlock; off <<= 1) {
+            const int other = static_cast<int>(threadIdx.x) >= off ? s_partial[threadIdx.x - off] : 0;
+            __syncthreads();
+            s_partial[threadIdx.x] = max(s_partial[threadIdx.x], other);
+            __syncthreads();
+        }
+        int run = threadIdx.x ? s_partial[threadIdx.x - 1] : 0;
+        for (int i = lo; i < hi; ++i) {
+            run = max(run, static_cast<int>(row_mark[i]));
+            row_mark[i] = static_cast<unsigned short>(run);
+        }
+        __syncthreads();
+    }
+
+    // SLOW path helpers (a batch whose entry range holds long rows): entries re-read per phase, rows searched
     auto row_of = [&](long long j) -> int {
         if (!Src::kSearchRows) return src.direct_row(j);
         int lo = row0, hi = row1;                  // offset(lo) <= j < offset(hi)
@@ -258,10 +303,6 @@ void batch_sort_kernel(Src src, BuildShape sh, int num_batches, int capacity,
         }
         return lo;
     };
-
-    // Every short-row entry of the batch, flat over the batch's entry range: coalesced loads, four in
-    // flight per thread.  The entry's row is looked up only where it is needed.
-    const long long entry0 = src.offset(row0), entry1 = src.offset(row1);
     auto for_each_entry = [&](auto&& body) {
         for (long long j0 = entry0 + threadIdx.x; j0 < entry1; j0 += 4 * kBuildBlock) {
             int c[4];
@@ -276,21 +317,46 @@ void batch_sort_kernel(Src src, BuildShape sh, int num_batches, int capacity,
             }
         }
     };
-    // -1 for an entry of a long row (PASS 0 also lists the row, once, at its first entry)
-    auto short_row_of = [&](long long j) {
-        const int row = row_of(j);
+    // the row of entry j, or -1 when that row is long (then listed once, at its first entry, and its entries
+    // are marked for the placing pass)
+    auto short_row = [&](long long j, int row) -> int {
         if (!sh.any_long) return row;
         const long long begin = src.offset(row);
         if (src.offset(row + 1) - begin <= sh.long_row) return row;
-        if (PASS == 0 && j == begin) long_rows[atomicAdd(num_long, 1)] = row;
+        if (j == begin) long_rows[atomicAdd(num_long, 1)] = row;
+        meta[j] = kMetaSkip;
         return -1;
     };
 
     // ---- histogram of the batch's short-row entries over the strips
-    for_each_entry([&](long long j, int c) {
-        if (sh.any_long && short_row_of(j) < 0) return;
-        atomicAdd(&bin_cursor[c >> sh.strip_shift], 1);
-    });
+    int my_col[kBuildPerThread], my_lrow[kBuildPerThread];
+    if (fast) {
+#pragma unroll
+        for (int u = 0; u < kBuildPerThread; ++u) {
+            const int idx = threadIdx.x + u * kBuildBlock;
+            my_col[u] = idx < span ? src.col(entry0 + idx) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kBuildPerThread; ++u) {
+            const int idx = threadIdx.x + u * kBuildBlock;
+            my_lrow[u] = 0;
+            if (my_col[u] >= 0) {
+                const long long j = entry0 + idx;
+                const int row = short_row(j, Src::kSearchRows ? row0 + row_mark[idx] : src.direct_row(j));
+                if (row < 0) {
+                    my_col[u] = -1;
+                } else {
+                    my_lrow[u] = row - tile_first;
+                    atomicAdd(&bin_cursor[my_col[u] >> sh.strip_shift], 1);
+                }
+            }
+        }
+    } else {
+        for_each_entry([&](long long j, int c) {
+            if (sh.any_long && short_row(j, row_of(j)) < 0) return;
+            atomicAdd(&bin_cursor[c >> sh.strip_shift], 1);
+        });
+    }
     __syncthreads();
 
     // ---- exclusive scan of the histogram: every thread owns a contiguous piece of the strips
@@ -321,111 +387,179 @@ void batch_sort_kernel(Src src, BuildShape sh, int num_batches, int capacity,
     const int total = s_partial[kBuildBlock - 1];
 
     // ---- fill the bins (order inside a bin is arbitrary here; the ranking below fixes it)
-    for_each_entry([&](long long j, int c) {
-        const int row = PASS == 0 && sh.any_long ? row_of(j) : short_row_of(j);
-        if (sh.any_long) {
-            if (PASS == 0) {       // (the histogram pass has listed the long rows already)
-                if (src.offset(row + 1) - src.offset(row) > sh.long_row) return;
-            } else if (row < 0) {
-                return;
-            }
-        }
-        const unsigned int lrow = static_cast<unsigned int>(row - tile_first);
+    auto put = [&](int c, int lrow, unsigned int from) {
         const int strip = c >> sh.strip_shift;
         const int u = atomicAdd(&bin_cursor[strip], 1);
-        keys[u] = (lrow << 16) | static_cast<unsigned int>(c - (strip << sh.strip_shift));
+        keys[u] = (static_cast<unsigned int>(lrow) << 16) | static_cast<unsigned int>(c - (strip << sh.strip_shift));
+        source[u] = from;
         bin_of[u] = static_cast<unsigned short>(strip);
-        if (PASS == 1) vals[u] = src.val(j);
-    });
+    };
+    if (fast) {
+#pragma unroll
+        for (int u = 0; u < kBuildPerThread; ++u) {
+            if (my_col[u] >= 0) put(my_col[u], my_lrow[u], threadIdx.x + u * kBuildBlock);
+        }
+    } else {
+        for_each_entry([&](long long j, int c) {
+            const int row = row_of(j);
+            if (sh.any_long && src.offset(row + 1) - src.offset(row) > sh.long_row) return;    // (listed above)
+            put(c, row - tile_first, static_cast<unsigned int>(j - entry0));
+        });
+    }
     __syncthreads();
 
     // ---- rank inside the bin = number of slots ordered before this one; the largest key among them is the
-    //      predecessor's.  Order: (row, column); a row that stores one column twice (legal CSR) is ordered by
-    //      the value bits next, so the layout stays a function of the matrix; fully identical entries — and
-    //      PASS 0, which needs counts only — fall back on the slot index.
-    auto before = [&](int v, unsigned int key_v, int u, unsigned int key_u) {
-        if (key_v != key_u) return key_v < key_u;
-        if (PASS == 1) {
-            const unsigned int a = __float_as_uint(vals[v]), b = __float_as_uint(vals[u]);
-            if (a != b) return a < b;
-        }
-        return v < u;
-    };
-    const GroupPlace* places = reinterpret_cast<const GroupPlace*>(groups) + static_cast<long long>(batch) * S;
-    for (int u = threadIdx.x; u < total; u += kBuildBlock) {
-        const int bin = bin_of[u];
-        const int lo = bin_start[bin], hi = bin_cursor[bin];
-        const unsigned int mine = keys[u];
-        int rank = 0;
-        unsigned int pred = 0;
-        bool has_pred = false;
-        for (int v = lo; v < hi; ++v) {
-            const unsigned int k = keys[v];
-            if (before(v, k, u, mine)) {
-                ++rank;
-                pred = has_pred ? max(pred, k) : k;
-                has_pred = true;
+    //      predecessor's.  Order: (row, column).  A row that stores one column twice (legal CSR) ties: such
+    //      slots are ordered by their source index (the CSR order), found in a second, rare, loop.
+    int my_rank[kBuildPerThread], my_need[kBuildPerThread], my_delta[kBuildPerThread];
+#pragma unroll
+    for (int k = 0; k < kBuildPerThread; ++k) {
+        const int u = threadIdx.x + k * kBuildBlock;
+        my_rank[k] = -1;
+        my_need[k] = 0;
+        my_delta[k] = 0;
+        if (u < total) {
+            const int bin = bin_of[u];
+            const int lo = bin_start[bin], hi = bin_cursor[bin];
+            const unsigned int mine = keys[u];
+            int rank = 0, ties = 0;
+            unsigned int pred = 0;
+            for (int v = lo; v < hi; ++v) {
+                const unsigned int key = keys[v];
+                const bool less = key < mine;
+                rank += less;
+                pred = less ? max(pred, key) : pred;
+                ties += key == mine;
             }
-        }
-        const int lrow = static_cast<int>(mine >> 16);
-        if (PASS == 0) {
-            // markers in front of the bin's first slot depend on the cell's earlier batches: cell_place_kernel adds them
-            if (has_pred) {
-                const int need = (lrow - static_cast<int>(pred >> 16)) / kSkip;
-                if (need) atomicAdd(&bin_escapes[bin], need);
+            if (ties > 1) {               // duplicate (row, column): order the twins by source index
+                const unsigned int me = source[u];
+                for (int v = lo; v < hi; ++v) {
+                    if (keys[v] == mine && source[v] < me) {
+                        ++rank;
+                        pred = mine;
+                    }
+                }
+            }
+            const int lrow = static_cast<int>(mine >> 16);
+            my_rank[k] = rank;
+            if (rank > 0) {
+                const int gap = lrow - static_cast<int>(pred >> 16);
+                my_need[k] = gap / kSkip;                 // skip markers in front of this slot
+                my_delta[k] = gap - my_need[k] * kSkip;
+                if (my_need[k]) atomicAdd(&bin_escapes[bin], my_need[k]);
             } else {
-                atomicOr(&bin_ends[bin], lrow << 16);                    // exactly one slot per bin has no predecessor
+                atomicOr(&bin_ends[bin], lrow << 16);     // exactly one slot per bin comes first ...
             }
-            if (rank == hi - lo - 1) atomicOr(&bin_ends[bin], lrow);     // ... and exactly one is the last
-        } else {
-            const int from = has_pred ? static_cast<int>(pred >> 16) : places[bin].prev_last;   // 0: the cell starts here
-            const int gap = lrow - from;
-            const int need = gap / kSkip;                                // skip markers in front of this slot
-            rank_of[u] = static_cast<unsigned short>(rank);
-            need_delta[u] = static_cast<unsigned short>((need << 8) | (gap - need * kSkip));
-            if (need) atomicAdd(&bin_escapes[bin], need);
+            if (rank == hi - lo - 1) atomicOr(&bin_ends[bin], lrow);     // ... and exactly one last
+            markers[u] = static_cast<unsigned char>(my_need[k]);
         }
     }
     __syncthreads();
 
-    if (PASS == 0) {
-        GroupCount* out = reinterpret_cast<GroupCount*>(groups) + static_cast<long long>(batch) * S;
-        for (int i = threadIdx.x; i < S; i += kBuildBlock) {
-            GroupCount g;
-            g.count = static_cast<unsigned short>(bin_cursor[i] - bin_start[i]);
-            g.first = static_cast<unsigned short>(static_cast<unsigned int>(bin_ends[i]) >> 16);
-            g.last = static_cast<unsigned short>(bin_ends[i] & 0xFFFF);
-            g.escapes = static_cast<unsigned short>(bin_escapes[i]);
-            uint2 packed;
-            __builtin_memcpy(&packed, &g, sizeof(g));
-            groups[static_cast<long long>(batch) * S + i] = packed;
+    // ---- the per-entry records for the placing pass
+#pragma unroll
+    for (int k = 0; k < kBuildPerThread; ++k) {
+        const int u = threadIdx.x + k * kBuildBlock;
+        if (u < total) {
+            const int bin = bin_of[u];
+            const unsigned int mine = keys[u];
+            unsigned int record;
+            if (my_rank[k] == 0) {
+                record = kMetaFirst | (mine >> 16);
+            } else {
+                int in_front = my_rank[k] + my_need[k];
+                if (bin_escapes[bin] != my_need[k]) {       // rare: other slots of this bin need markers too
+                    const unsigned int me = source[u];
+                    for (int v = bin_start[bin]; v < bin_cursor[bin]; ++v) {
+                        const unsigned int key = keys[v];
+                        if (key < mine || (key == mine && source[v] < me)) in_front += markers[v];
+                    }
+                }
+                record = (static_cast<unsigned int>(in_front) << 16) | (static_cast<unsigned int>(my_need[k]) << 8) |
+                         static_cast<unsigned int>(my_delta[k]);
+            }
+            meta[entry0 + source[u]] = record;
         }
-        (void)out;
-        return;
     }
+    for (int i = threadIdx.x; i < S; i += kBuildBlock) {
+        GroupCount g;
+        g.count = static_cast<unsigned short>(bin_cursor[i] - bin_start[i]);
+        g.first = static_cast<unsigned short>(static_cast<unsigned int>(bin_ends[i]) >> 16);
+        g.last = static_cast<unsigned short>(bin_ends[i] & 0xFFFF);
+        g.escapes = static_cast<unsigned short>(bin_escapes[i]);
+        uint2 packed;
+        __builtin_memcpy(&packed, &g, sizeof(g));
+        groups[static_cast<long long>(batch) * S + i] = packed;
+    }
+}
 
-    // ---- PASS 1 write-out: slot position = cell begin + group offset + rank + markers in front of it
-    for (int u = threadIdx.x; u < total; u += kBuildBlock) {
-        const int bin = bin_of[u];
-        const unsigned int mine = keys[u];
-        const int rank = rank_of[u];
-        const int need = need_delta[u] >> 8;
-        int markers_before = 0;
-        if (bin_escapes[bin] != 0) {                 // rare: some slot of this bin needs markers
-            for (int v = bin_start[bin]; v < bin_cursor[bin]; ++v) {
-                if (before(v, keys[v], u, mine)) markers_before += need_delta[v] >> 8;
+// The placing pass: no sorting any more — every entry of the batch goes to cell begin + group offset + the
+// position the ranking pass recorded, preceded by its skip markers.  Dynamic LDS: 12 bytes per strip (the
+// batch's group records and its tile's cell begins).
+template <typename Src>
+__global__ __launch_bounds__(kBuildBlock)
+void batch_place_kernel(Src src, BuildShape sh, int num_batches,
+                        const int* __restrict__ batch_row, const int* __restrict__ batch_tile,
+                        const uint2* __restrict__ groups,              // [batches * strips] GroupPlace
+                        const unsigned int* __restrict__ meta, const int* __restrict__ offs,
+                        float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
+                        unsigned char* __restrict__ a_drow) {
+    extern __shared__ int place_lds[];
+    const int batch = xcd_contiguous(blockIdx.x, num_batches);
+    if (batch < 0) return;
+    const int S = sh.num_strips;
+    uint2* place = reinterpret_cast<uint2*>(place_lds);
+    int* cell_begin = place_lds + 2 * S;
+    const int tile = batch_tile[batch];
+    const int row0 = batch_row[batch];
+    const long long tile_end = min(static_cast<long long>(tile + 1) * sh.tile_rows, static_cast<long long>(sh.num_rows));
+    const int row1 = batch + 1 < num_batches && batch_tile[batch + 1] == tile ? batch_row[batch + 1]
+                                                                                : static_cast<int>(tile_end);
+    const long long entry0 = src.offset(row0), entry1 = src.offset(row1);
+    for (int i = threadIdx.x; i < S; i += kBuildBlock) {
+        place[i] = groups[static_cast<long long>(batch) * S + i];
+        cell_begin[i] = offs[static_cast<long long>(i) * sh.num_tiles + tile];
+    }
+    __syncthreads();
+    for (long long j0 = entry0 + threadIdx.x; j0 < entry1; j0 += 4 * kBuildBlock) {
+        int c[4];
+        unsigned int m[4];
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long j = j0 + static_cast<long long>(u) * kBuildBlock;
+            c[u] = -1;
+            if (j < entry1) {
+                c[u] = src.col(j);
+                m[u] = meta[j];
+                v[u] = a_val ? src.val(j) : 0.0f;
             }
         }
-        const long long cell = static_cast<long long>(bin) * sh.num_tiles + tile;
-        const long long at = static_cast<long long>(offs[cell]) + places[bin].rel + rank + markers_before;
-        for (int k = 0; k < need; ++k) {
-            if (a_val) a_val[at + k] = 0.0f;
-            a_lcol[at + k] = 0;
-            a_drow[at + k] = kSkip;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c[u] < 0 || m[u] == kMetaSkip) continue;
+            const int strip = c[u] >> sh.strip_shift;
+            GroupPlace p;
+            __builtin_memcpy(&p, &place[strip], sizeof(p));
+            long long at = static_cast<long long>(cell_begin[strip]) + p.rel;
+            int need, delta;
+            if (m[u] & kMetaFirst) {
+                need = p.lead;
+                delta = static_cast<int>(m[u] & 0xFFFF) - p.prev_last - need * kSkip;
+            } else {
+                need = (m[u] >> 8) & 0xFF;
+                delta = m[u] & 0xFF;
+                at += p.lead + (m[u] >> 16) - need;
+            }
+            for (int k = 0; k < need; ++k) {
+                if (a_val) a_val[at + k] = 0.0f;
+                a_lcol[at + k] = 0;
+                a_drow[at + k] = kSkip;
+            }
+            if (a_val) a_val[at + need] = v[u];
+            a_lcol[at + need] = static_cast<unsigned short>(c[u] - (strip << sh.strip_shift));
+            a_drow[at + need] = static_cast<unsigned char>(delta);
         }
-        if (a_val) a_val[at + need] = vals[u];
-        a_lcol[at + need] = static_cast<unsigned short>(mine & 0xFFFF);
-        a_drow[at + need] = static_cast<unsigned char>(need_delta[u] & 0xFF);
     }
 }
 
@@ -449,9 +583,10 @@ void cell_place_kernel(int num_tiles, int num_strips, const int* __restrict__ ti
             GroupPlace p;
             p.rel = total;
             p.prev_last = static_cast<unsigned short>(last);
-            p.unused = 0;
+            p.lead = 0;
             if (g.count) {
-                total += g.count + g.escapes + (g.first - last) / kSkip;
+                p.lead = static_cast<unsigned short>((g.first - last) / kSkip);
+                total += g.count + g.escapes + p.lead;
                 last = g.last;
                 mine += g.count;
             }
@@ -606,6 +741,7 @@ void strip_weight_kernel(int first_strip, int slot_limit, const int* __restrict_
         if (a_drow[q] != kSkip) bad |= __float_as_uint(ws[a_lcol[q]]) != __float_as_uint(a_val[q]);
     }
     if (bad) *differs = 1;
+    if (!weight) return;                 // sampling round: only the verdict is wanted
     const long long base = static_cast<long long>(strip) * W;
     for (int i = threadIdx.x; i < W && base + i < num_cols; i += 1024) weight[base + i] = ws[i];
 }
@@ -899,9 +1035,9 @@ __device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_in
         const unsigned int i = static_cast<unsigned int>(ps.done) + E * lane;
 #pragma unroll
         for (int j = 0; j < kRuns; ++j) {
-            // lanes past the run's end re-read its last 4 slots (same cache line, no extra traffic) and a lane
+            // lanes past the run's end re-read its last 4 (E = 2: 2) slots (same cache line, no extra traffic) and a lane
             // that straddles the end (E = 8, length 4 mod 8) reads 4 slots of the next cell: both masked below
-            const unsigned int last = static_cast<unsigned int>(max(ps.len[j] - 4, 0));
+            const unsigned int last = static_cast<unsigned int>(max(ps.len[j] - (E < 4 ? E : 4), 0));
             const unsigned int at = min(i, last);
             const char* products = reinterpret_cast<const char*>(prod + ps.begin[j]);
             const char* deltas = reinterpret_cast<const char*>(a_drow + ps.begin[j]);
@@ -1246,10 +1382,12 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     int *strip_begin = nullptr;
     long long* block_sum = nullptr;    // scan scratch; [blocks] sums, then [blocks] grand total, [blocks + 1] entry count
     uint2* groups = nullptr;
+    unsigned int* meta = nullptr;      // per-entry records between the ranking and the placing pass
     auto cleanup = [&](hipError_t e) {
         for (void* q : {static_cast<void*>(d_small), static_cast<void*>(tile_batch), static_cast<void*>(batch_row),
                         static_cast<void*>(batch_tile), static_cast<void*>(cell_slots), static_cast<void*>(offs),
-                        static_cast<void*>(strip_begin), static_cast<void*>(block_sum), static_cast<void*>(groups)}) {
+                        static_cast<void*>(strip_begin), static_cast<void*>(block_sum), static_cast<void*>(groups),
+                        static_cast<void*>(meta)}) {
             if (q) (void)hipFree(q);
         }
         return e;
@@ -1270,7 +1408,7 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     const int lds_bytes = S <= 1024 ? kBuildLdsSmall : kBuildLdsLarge;
     int capacity = (lds_bytes - kBuildBinWords * 4 * S) / kBuildEntryBytes / 64 * 64;
     if (capacity < 512) return cleanup(hipErrorInvalidValue);
-    capacity = std::min(capacity, 65535 / 2);        // group counts are 16-bit
+    capacity = std::min(capacity, kBuildMaxCapacity);        // what a workgroup's threads keep in registers
     max_row_kernel<<<std::min(2048, (plan->num_rows + kBlock - 1) / kBlock), kBlock, 0, s>>>(dev_src, plan->num_rows, d_small);
     int longest = 0;
     e = hipMemcpyAsync(&longest, d_small, sizeof(int), hipMemcpyDeviceToHost, s);
@@ -1300,21 +1438,19 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     e = dev_alloc(&batch_row, static_cast<long long>(num_batches) + 1);
     if (e == hipSuccess) e = dev_alloc(&batch_tile, num_batches);
     if (e == hipSuccess) e = dev_alloc(&groups, group_count);
+    if (e == hipSuccess) e = dev_alloc(&meta, plan->csr_nnz);
     if (e == hipSuccess && has_long_path) {
         e = dev_alloc(&plan->long_rows, plan->csr_nnz / std::max(plan->long_row, 1) + 1);
     }
     if (e != hipSuccess) return cleanup(e);
     batch_rows_kernel<<<T, kBlock, 0, s>>>(dev_src, sh, tile_batch, batch_row, batch_tile);
 
-    // ---- pass 0: group sizes; cell placement; scan
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_sort_kernel<Src, 0>),
+    // ---- ranking pass: group sizes + per-entry records; cell placement; scan
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_rank_kernel<Src>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_sort_kernel<Src, 1>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return cleanup(e);
-    batch_sort_kernel<Src, 0><<<xcd_grid(num_batches), kBuildBlock, lds_bytes, s>>>(
-        dev_src, sh, num_batches, capacity, batch_row, batch_tile, groups, nullptr, nullptr, nullptr, nullptr,
-        plan->long_rows, d_small + 1);
+    batch_rank_kernel<Src><<<xcd_grid(num_batches), kBuildBlock, lds_bytes, s>>>(
+        dev_src, sh, num_batches, capacity, batch_row, batch_tile, groups, meta, plan->long_rows, d_small + 1);
     unsigned long long* entry_total = reinterpret_cast<unsigned long long*>(block_sum + scan_blocks + 1);
     e = hipMemsetAsync(entry_total, 0, sizeof(unsigned long long), s);
     cell_place_kernel<<<static_cast<int>((cells + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, S, tile_batch, groups, cell_slots,
@@ -1334,7 +1470,7 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     plan->entries = totals[1];
     plan->num_long = num_long;
 
-    // ---- pass 1: write the slots
+    // ---- placing pass: write the slots
     if (want_values) e = dev_alloc(&plan->a_val, plan->nnz + 8);
     // + 8: the 16-byte loads of a run's last group stay inside the allocation whatever its alignment
     if (e == hipSuccess) e = dev_alloc(&plan->a_lcol, plan->nnz + 8);
@@ -1342,9 +1478,8 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     if (e == hipSuccess) e = dev_alloc(&plan->cells_t, 2 * cells);
     if (e != hipSuccess) return cleanup(e);
     if (plan->nnz > 0) {
-        batch_sort_kernel<Src, 1><<<xcd_grid(num_batches), kBuildBlock, lds_bytes, s>>>(
-            dev_src, sh, num_batches, capacity, batch_row, batch_tile, groups, offs, plan->a_val, plan->a_lcol,
-            plan->a_drow, nullptr, nullptr);
+        batch_place_kernel<Src><<<xcd_grid(num_batches), kBuildBlock, 12 * static_cast<size_t>(S), s>>>(
+            dev_src, sh, num_batches, batch_row, batch_tile, groups, meta, offs, plan->a_val, plan->a_lcol, plan->a_drow);
         cell_padding_kernel<<<static_cast<int>(std::min<long long>((cells + kBlock - 1) / kBlock, 4096)), kBlock, 0, s>>>(
             cell_slots, offs, cells, plan->a_val, plan->a_lcol, plan->a_drow);
     }
@@ -1474,25 +1609,26 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     if (fold && plan->nnz > 0) {
         int* differs = nullptr;
         e = dev_alloc(&differs, 1);
-        if (e == hipSuccess) e = dev_alloc(&plan->col_weight, plan->num_cols);
         if (e == hipSuccess) e = hipMemsetAsync(differs, 0, sizeof(int), s);
         int host_differs = 1;
-        auto probe = [&](int first, int count, int limit) {
+        auto probe = [&](int first, int count, int limit, float* weight) {
             switch (plan->strip_cols) {
-                case 4096:  strip_weight_kernel<4096><<<count, 1024, 0, s>>>(first, limit, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
-                case 8192:  strip_weight_kernel<8192><<<count, 1024, 0, s>>>(first, limit, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
-                case 16384: strip_weight_kernel<16384><<<count, 1024, 0, s>>>(first, limit, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
-                default:    strip_weight_kernel<32768><<<count, 1024, 0, s>>>(first, limit, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, plan->col_weight, differs); break;
+                case 4096:  strip_weight_kernel<4096><<<count, 1024, 0, s>>>(first, limit, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, weight, differs); break;
+                case 8192:  strip_weight_kernel<8192><<<count, 1024, 0, s>>>(first, limit, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, weight, differs); break;
+                case 16384: strip_weight_kernel<16384><<<count, 1024, 0, s>>>(first, limit, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, weight, differs); break;
+                default:    strip_weight_kernel<32768><<<count, 1024, 0, s>>>(first, limit, strip_begin, plan->num_cols, plan->a_val, plan->a_lcol, plan->a_drow, weight, differs); break;
             }
         };
-        // round 0: the first 32 K slots of up to 64 strips (with arbitrary values some column repeats there and
-        // the matter is settled); round 1: everything
+        // round 0: the first 32 K slots of up to 64 strips, verdict only (with arbitrary values some column
+        // repeats there and the matter is settled before anything is allocated); round 1: everything
         const int sample = std::min(plan->num_strips, 64);
         for (int round = 0; round < 2 && e == hipSuccess; ++round) {
             if (round == 0) {
-                probe(0, sample, 32768);
+                probe(0, sample, 32768, nullptr);
             } else {
-                probe(0, plan->num_strips, 0x7fffffff);
+                e = dev_alloc(&plan->col_weight, plan->num_cols);
+                if (e != hipSuccess) break;
+                probe(0, plan->num_strips, 0x7fffffff, plan->col_weight);
                 if (plan->num_long_chunks > 0) {
                     const int grid = (plan->num_long_chunks + kBlock / 64 - 1) / (kBlock / 64);
                     long_row_weight_kernel<0><<<grid, kBlock, 0, s>>>(plan->long_chunks, plan->num_long_chunks, plan->csr_cols,
@@ -1511,7 +1647,7 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         if (differs) (void)hipFree(differs);
         if (e != hipSuccess) return fail_with_strip(e);
         if (host_differs) {
-            (void)hipFree(plan->col_weight);
+            if (plan->col_weight) (void)hipFree(plan->col_weight);
             plan->col_weight = nullptr;
         } else {
             (void)hipFree(plan->a_val);           // folded: phase 1 reads weights, not values

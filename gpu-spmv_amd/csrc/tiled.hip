@@ -30,7 +30,7 @@
 //   folding : when every stored entry of a column has the same bits, the value stream is dropped
 //        and phase 1 gathers w_j * x_j from LDS (strip_weight_kernel, FOLD instantiation).
 //   both phases walk their work lists in per-XCD contiguous slices (xcd_contiguous).
-//   long rows (more than min(2048, 2 or 4 entries per strip)) would make many lanes fight over one
+//   long rows (more than min(4096, 8 entries per strip)) would make many lanes fight over one
 //        LDS word; they are left out of the cells and summed in 512-entry chunks by extra
 //        wavefronts of the phase-1 grid (direct gather) into a side vector that seeds the tiles.
 //   build : two passes of one kernel over batches of <= ~5.5 K entries (rows of ONE tile): the batch is
@@ -70,7 +70,7 @@ using namespace dev;
 //   R = any multiple of 64 in [64, kMaxTileRows]: dynamic LDS in phase 2
 constexpr int kMaxItemEntries = 65536;   // phase-1 work item size bounds (entries)
 constexpr int kMinItemEntries = 4096;
-constexpr int kMaxLongRow = 2048;     // rows longer than min(this, 2 or 4 entries per strip) bypass the cells
+constexpr int kMaxLongRow = 4096;     // rows longer than min(this, 8 entries per strip) bypass the cells
 constexpr int kLongChunk = 512;       // entries per wavefront of the long-row path
 constexpr long long kMaxCells = 1LL << 26;
 constexpr long long kTargetRun = 128;        // wanted mean entries per cell (run length seen by phase 2)
@@ -1518,13 +1518,12 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     plan->num_strips = (src.cols + plan->strip_cols - 1) / plan->strip_cols;
     plan->num_tiles = (src.rows + plan->tile_rows - 1) / plan->tile_rows;
     const long long cells = static_cast<long long>(plan->num_strips) * plan->num_tiles;
-    // A row spreads over the strips; once it averages more than ~2 entries per cell its lanes
-    // start to collide on one LDS word in phase 2, so such rows take the direct path instead.
-    // Where the line sits depends on what the direct path's gathers cost: with x inside the L2s
-    // (<= 8 MB) they are cheap and 2 entries per cell is the limit (C4, 62 strips: 124 entries 53 us,
-    // 248 entries 55 us); with a large x every gather is a fabric request and rows stay in the cells
-    // longer (10 M x 10 M power-law matrix, 611 strips: limit 1024 475 us, 2048 449 us, 4096 454 us).
-    int long_factor = static_cast<long long>(src.cols) * 4 > (8LL << 20) ? 4 : 2;
+    // A row spreads over the strips; rows with many entries per cell make lanes meet on one LDS word in phase 2,
+    // so the longest rows take the direct path instead (512-entry chunks, direct gather, seeds).  With the
+    // compare-and-swap add of round 1 the line sat at 2-4 entries per strip; the hardware ds_add_f64 takes
+    // collisions far better (profiles/r02_long_row_sweep.txt, C4 = 1 M power-law rows, 62 strips: limit 124
+    // entries 49.5 us, 248: 47.2, 496: 44.2, unlimited 47.8; 10 M x 10 M power-law: 426 / 435 / 416 / 402 us).
+    int long_factor = 8;
     if (const char* env = std::getenv("SPMV_TILED_LONG_FACTOR")) long_factor = std::max(1, std::atoi(env));
     int long_cap = kMaxLongRow;
     if (const char* env = std::getenv("SPMV_TILED_LONG_CAP")) long_cap = std::max(64, std::atoi(env));

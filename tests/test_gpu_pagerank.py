@@ -264,9 +264,8 @@ def test_pagerank_switches_to_the_tiled_engine_mid_run(gpu, oracle):
 
 
 def test_repeated_calls_on_a_power_law_graph_with_long_rows(gpu, oracle):
-    """In-degrees follow a power law, so some rows are too long for the cells of the tiled engine: the
-    first few thousand are summed through LDS accumulators in phase 1, the rest by the direct path,
-    both via the seed vector.  A second pagerank() on the same matrix, and an SpMV after it, must not
+    """In-degrees follow a power law, so some rows are too long for the cells of the tiled engine: they are
+    summed by the direct path (extra wavefronts of the phase-1 grid) into the seed vector.  A second pagerank() on the same matrix, and an SpMV after it, must not
     see anything the first call's run-ahead step left behind."""
     n = 400_000
     lens = gpu.synth.power_law_lengths(31, n, max_len=20000, n_cols=n)
@@ -275,7 +274,7 @@ def test_repeated_calls_on_a_power_law_graph_with_long_rows(gpu, oracle):
     A = upload(gpu, rp, ci, va, n)
     first = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
     info = gpu.csr_tiled_info(A)
-    assert info is not None and info["long_rows"] > 2048                   # both long-row paths are in use
+    assert info is not None and info["long_rows"] > 100                    # the long-row (direct, seeded) path is in use
     second = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
     for r in (first, second):
         assert_parity(gpu, oracle, A, rp, ci, va, n, r)

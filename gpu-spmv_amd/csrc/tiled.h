@@ -44,7 +44,9 @@ struct TiledPlan {
     int    long_row = 1024;         // rows with more entries than this are "long"
     int*   long_chunks = nullptr;   // [3 * num_long_chunks] (row, begin, end) over the CSR arrays
     int    num_long_chunks = 0;
-    float* seed = nullptr;          // [num_rows] zeros except the long rows' sums (null if none)
+    int*   long_first = nullptr;    // [num_long + 1] first chunk of every long row
+    float* long_sums = nullptr;     // [num_long_chunks] per-chunk partial sums of the current SpMV
+    int*   tile_long = nullptr;     // [num_tiles + 1] first long row of every tile (index into long_rows)
     const int*   csr_row_ptrs = nullptr;   // borrowed from the matrix
     const int*   csr_cols = nullptr;
     const float* csr_vals = nullptr;

@@ -32,7 +32,7 @@
 //   both phases walk their work lists in per-XCD contiguous slices (xcd_contiguous).
 //   long rows (more than min(4096, 8 entries per strip)) would make many lanes fight over one
 //        LDS word; they are left out of the cells and summed in 512-entry chunks by extra
-//        wavefronts of the phase-1 grid (direct gather) into a side vector that seeds the tiles.
+//        wavefronts of the phase-1 grid (direct gather); their chunk sums seed the tiles in phase 2.
 //   build : two passes of one kernel over batches of <= ~5.5 K entries (rows of ONE tile): the batch is
 //        binned by strip in LDS, ranked inside every bin by (row, column), and — second pass — written
 //        to its cells at offsets fixed by a scan over (strip, tile, batch) counts.  No global atomics,
@@ -794,25 +794,24 @@ void cell_table_kernel(const int* __restrict__ offs, int num_strips, int num_til
 
 // ------------------------------------------------------------------------ phase 1 ----
 // Rows too long for the cells are cut into chunks of kLongChunk entries; one wavefront per
-// chunk sums it by direct gather and adds the sum atomically into seed[row].  seed is zero on
-// entry (zeroed at build; phase 2 re-zeroes what it consumes).  These wavefronts ride in extra
-// workgroups at the head of the phase-1 grid, so they overlap the expansion at no launch cost.
+// chunk sums it by direct gather into its own slot; phase 2's tile start then adds a long row's chunk sums in
+// chunk order (no atomics, no state between calls: the same bits on every run).  The chunk wavefronts ride in
+// extra workgroups at the head of the phase-1 grid, so they overlap the expansion at no launch cost.
 struct LongRows {
     const int* chunks;        // (row, begin, end) triples over the CSR arrays
     int num_chunks;
     long long nnz;
     const int* cols;
     const float* vals;
-    float* seed;
+    float* chunk_sum;         // [num_chunks] one partial sum per chunk (no atomics: long_rows_finish_kernel adds them in order)
 };
 
 __device__ __forceinline__ void long_row_chunk(const LongRows& lr, int which, const float* __restrict__ x) {
     if (which >= lr.num_chunks) return;
-    const int row = lr.chunks[3 * which];
     float acc = row_partial_dot<64>(lr.chunks[3 * which + 1], lr.chunks[3 * which + 2], threadIdx.x & 63, lr.nnz,
                                     lr.cols, lr.vals, x);
     acc = group_sum<64>(acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&lr.seed[row], acc);
+    if ((threadIdx.x & 63) == 0) lr.chunk_sum[which] = acc;
 }
 
 // FOLD: the plan holds one weight per column instead of a value per entry; the strip is staged
@@ -826,9 +825,7 @@ void tiled_expand_kernel(const int* __restrict__ items, int num_items, int long_
                          const float* __restrict__ x, int num_cols,
                          float* __restrict__ prod, LongRows long_rows,
                          const PrState* __restrict__ state) {
-    // PageRank steps enqueued past convergence must leave the seed vector alone: phase 2 returns
-    // before consuming it, and the long-row wavefronts ADD into it (a later call on the same
-    // matrix would start from stale sums)
+    // PageRank steps enqueued past convergence are no-ops
     if (state && state->done) return;
     if (static_cast<int>(blockIdx.x) < long_blocks) {     // the long-row workgroups go first (latency-bound)
         constexpr int kPerBlock = kExpandBlock / 64;
@@ -943,8 +940,15 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
     return v;
 }
 
-// Fills the LDS tile with the sums of this tile's rows.  `seed` (may be null) holds the
-// long rows' sums and zeros elsewhere.  The tile accumulates in DOUBLE: every fp32 product is added
+// the long rows (direct path): which of them fall into which tile, and where their chunk sums are
+struct LongSeeds {
+    const int* rows;          // [num_long] ascending
+    const int* first_chunk;   // [num_long + 1]
+    const int* tile_first;    // [num_tiles + 1] first long row of every tile (null: no long rows)
+    const float* chunk_sum;   // [num_chunks] written by phase 1 of this SpMV
+};
+
+// Fills the LDS tile with the sums of this tile's rows; the long rows' sums come from their chunk sums.  The tile accumulates in DOUBLE: every fp32 product is added
 // exactly as often as fp64 allows (products of one row rarely span more than 29 binades), so the row
 // sums no longer depend on the order in which the wavefronts' adds meet, and they are rounded to
 // fp32 once, on the way out.
@@ -954,16 +958,17 @@ __device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_in
                                                 const int2* __restrict__ cells_t,
                                                 const float* __restrict__ prod,
                                                 const unsigned char* __restrict__ a_drow,
-                                                float* __restrict__ seed) {
+                                                const LongSeeds seeds) {
     __shared__ double spare[64];           // where a lane's slots without an entry "add" (never read)
     const long long first = static_cast<long long>(tile_index) * R;
-    for (int i = threadIdx.x; i < R; i += kReduceBlock) {
-        float v = 0.0f;
-        if (seed && first + i < num_rows) {
-            v = seed[first + i];
-            if (v != 0.0f) seed[first + i] = 0.0f;      // leave the seed vector clean for the next call
+    for (int i = threadIdx.x; i < R; i += kReduceBlock) tile[i] = 0.0;
+    if (seeds.tile_first) {
+        __syncthreads();
+        for (int k = seeds.tile_first[tile_index] + threadIdx.x; k < seeds.tile_first[tile_index + 1]; k += kReduceBlock) {
+            double total = 0.0;                         // a long row's chunk sums, in chunk order
+            for (int c = seeds.first_chunk[k]; c < seeds.first_chunk[k + 1]; ++c) total += static_cast<double>(seeds.chunk_sum[c]);
+            tile[seeds.rows[k] - first] = total;
         }
-        tile[i] = static_cast<double>(v);
     }
     __syncthreads();
 
@@ -1111,12 +1116,12 @@ __global__ __launch_bounds__(kReduceBlock, kReduceBlock / 128)     // two tiles 
 void tiled_reduce_kernel(int R, int num_tiles, const int2* __restrict__ cells_t, int num_strips,
                          const float* __restrict__ prod,
                          const unsigned char* __restrict__ a_drow,
-                         float* __restrict__ seed,
+                         const LongSeeds seeds,
                          int num_rows, float* __restrict__ y) {
     extern __shared__ double tile[];
     const int tile_index = xcd_contiguous(blockIdx.x, num_tiles);
     if (tile_index < 0) return;
-    tile_accumulate<kReduceBlock, E, kRuns>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_drow, seed);
+    tile_accumulate<kReduceBlock, E, kRuns>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_drow, seeds);
     const long long first = static_cast<long long>(tile_index) * R;
     for (int i = threadIdx.x; i < R && first + i < num_rows; i += kReduceBlock) y[first + i] = static_cast<float>(tile[i]);
 }
@@ -1127,7 +1132,7 @@ __global__ __launch_bounds__(kReduceBlock, kReduceBlock / 128)
 void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__ cells_t, int num_strips,
                                   const float* __restrict__ prod,
                                   const unsigned char* __restrict__ a_drow,
-                                  float* __restrict__ seed,
+                                  const LongSeeds seeds,
                                   int local_rows, int row_offset, int n_global,
                                   const float* __restrict__ r_old, float* __restrict__ r_new,
                                   const unsigned char* __restrict__ dangling, float damping,
@@ -1137,7 +1142,7 @@ void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__
     extern __shared__ double tile[];
     const int tile_index = xcd_contiguous(blockIdx.x, num_tiles);
     if (tile_index < 0) return;
-    tile_accumulate<kReduceBlock, E, kRuns>(tile, R, tile_index, num_strips, local_rows, cells_t, prod, a_drow, seed);
+    tile_accumulate<kReduceBlock, E, kRuns>(tile, R, tile_index, num_strips, local_rows, cells_t, prod, a_drow, seeds);
 
     const float teleport = __fdiv_rn(1.0f - damping, static_cast<float>(n_global));
     const float dangling_term = __fdiv_rn(__fmul_rn(damping, state->dangling_sum),
@@ -1214,7 +1219,7 @@ void choose_shape(long long num_rows, long long num_cols, long long nnz, int* st
 
 template <int W, int BLOCK>
 hipError_t launch_expand_as(const TiledPlan& plan, const float* d_x, const PrState* d_state, hipStream_t s) {
-    const LongRows lr{plan.long_chunks, plan.num_long_chunks, plan.csr_nnz, plan.csr_cols, plan.csr_vals, plan.seed};
+    const LongRows lr{plan.long_chunks, plan.num_long_chunks, plan.csr_nnz, plan.csr_cols, plan.csr_vals, plan.long_sums};
     const int long_blocks = xcd_grid((plan.num_long_chunks + BLOCK / 64 - 1) / (BLOCK / 64));
     const int grid = long_blocks + xcd_grid(plan.num_items);
     if (plan.col_weight) {
@@ -1237,6 +1242,10 @@ hipError_t launch_expand(const TiledPlan& plan, const float* d_x, const PrState*
     }
 }
 
+LongSeeds long_seeds(const TiledPlan& plan) {
+    return LongSeeds{plan.long_rows, plan.long_first, plan.num_long > 0 ? plan.tile_long : nullptr, plan.long_sums};
+}
+
 template <int BLOCK, int E, int kRuns>
 hipError_t launch_reduce_as(const TiledPlan& plan, float* d_y, hipStream_t s) {
     const size_t lds = static_cast<size_t>(plan.tile_rows) * sizeof(double);
@@ -1245,7 +1254,7 @@ hipError_t launch_reduce_as(const TiledPlan& plan, float* d_y, hipStream_t s) {
     if (e != hipSuccess) return e;
     tiled_reduce_kernel<BLOCK, E, kRuns><<<xcd_grid(plan.num_tiles), BLOCK, lds, s>>>(
         plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_drow,
-        plan.seed, plan.num_rows, d_y);
+        long_seeds(plan), plan.num_rows, d_y);
     return hipGetLastError();
 }
 
@@ -1268,7 +1277,7 @@ hipError_t launch_pagerank_reduce_as(const TiledPlan& plan, int row_offset, int 
     if (e != hipSuccess) return e;
     tiled_pagerank_reduce_kernel<BLOCK, E, kRuns><<<xcd_grid(plan.num_tiles), BLOCK, lds, s>>>(
         plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_drow,
-        plan.seed, plan.num_rows, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
+        long_seeds(plan), plan.num_rows, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
         d_block_partials, push);
     return hipGetLastError();
 }
@@ -1363,7 +1372,7 @@ hipError_t tiled_build(const ELLMatrix* A, TiledPlan** out, hipStream_t s) {
 void tiled_free(TiledPlan* p) {
     if (!p) return;
     void* owned[] = {p->a_val, p->a_lcol, p->a_drow, p->prod, p->cells_t, p->items, p->long_rows, p->long_chunks,
-                     p->seed, p->col_weight};
+                     p->long_first, p->long_sums, p->tile_long, p->col_weight};
     for (void* q : owned) if (q) (void)hipFree(q);
     delete p;
 }
@@ -1580,7 +1589,9 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
             e = hipMemcpy(all_ptrs.data(), A->d_row_ptrs, all_ptrs.size() * sizeof(int), hipMemcpyDeviceToHost);
             host_ptrs = all_ptrs.data();
         }
+        std::vector<int> first_chunk;
         for (int row : rows) {
+            first_chunk.push_back(static_cast<int>(chunks.size() / 3));
             int span[2] = {0, 0};
             if (host_ptrs) {
                 span[0] = host_ptrs[row];
@@ -1595,11 +1606,26 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
             }
         }
         plan->num_long_chunks = static_cast<int>(chunks.size() / 3);
+        first_chunk.push_back(plan->num_long_chunks);
+        if (e == hipSuccess) e = dev_alloc(&plan->long_first, static_cast<long long>(first_chunk.size()));
+        if (e == hipSuccess) e = hipMemcpy(plan->long_first, first_chunk.data(), first_chunk.size() * sizeof(int),
+                                           hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = dev_alloc(&plan->long_sums, plan->num_long_chunks);
         if (e == hipSuccess) e = dev_alloc(&plan->long_chunks, static_cast<long long>(chunks.size()));
         if (e == hipSuccess) e = hipMemcpy(plan->long_chunks, chunks.data(), chunks.size() * sizeof(int),
                                            hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = dev_alloc(&plan->seed, plan->num_rows);
-        if (e == hipSuccess) e = hipMemsetAsync(plan->seed, 0, static_cast<size_t>(plan->num_rows) * sizeof(float), s);
+        if (e == hipSuccess) {          // first long row of every tile (the list is ascending)
+            std::vector<int> tile_long(static_cast<size_t>(plan->num_tiles) + 1);
+            size_t at = 0;
+            for (int t = 0; t <= plan->num_tiles; ++t) {
+                const long long bound = static_cast<long long>(t) * plan->tile_rows;
+                while (at < rows.size() && rows[at] < bound) ++at;
+                tile_long[t] = static_cast<int>(at);
+            }
+            e = dev_alloc(&plan->tile_long, static_cast<long long>(tile_long.size()));
+            if (e == hipSuccess) e = hipMemcpy(plan->tile_long, tile_long.data(), tile_long.size() * sizeof(int),
+                                               hipMemcpyHostToDevice);
+        }
         if (e != hipSuccess) return fail_with_strip(e);
     }
 
@@ -1689,7 +1715,7 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     if (e != hipSuccess) return fail(e);
 
     plan->plan_bytes = plan->nnz * (4 /*prod*/ + 2 + 1 + (plan->a_val ? 4 : 0)) + cells * 8 +
-                       (plan->col_weight ? 4LL * plan->num_cols : 0) + (plan->seed ? 4LL * plan->num_rows : 0) +
+                       (plan->col_weight ? 4LL * plan->num_cols : 0) +
                        12LL * plan->num_items + 12LL * plan->num_long_chunks;
     plan->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     *out = plan;
@@ -1709,8 +1735,8 @@ hipError_t tiled_pagerank_step(const TiledPlan& plan, int row_offset, int n_glob
                                const unsigned char* d_dangling, float damping,
                                const PrState* d_state, double* d_block_partials,
                                const PushTargets& push, hipStream_t s) {
-    // After convergence both kernels return at once: r_new, the product stream and the seed vector
-    // stay as the last committed step left them.
+    // After convergence both kernels return at once: r_new and the product stream stay as the last committed
+    // step left them.
     const hipError_t e = launch_expand(plan, d_r_old, d_state, s);   // phase 1 + the long rows (no-op once done)
     if (e != hipSuccess) return e;
     return launch_pagerank_reduce(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,

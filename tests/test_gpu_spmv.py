@@ -5,6 +5,8 @@ than the reference's 1e-6, tests/test_spmv.cu:18-35).  VECTOR_CSR and MERGE_PATH
 reorder a row's sum and are held to 1e-5 (BASELINE.json north_star) — relative to
 |y_i| when the row has no cancellation (non-negative data: test_nonnegative_*),
 and relative to max(|y_i|, sum_j |a_ij x_j|) on signed data (conftest.reorder_err)."""
+import importlib
+
 import numpy as np
 import pytest
 
@@ -297,6 +299,34 @@ def _tiled_with_info(spmv, rp, ci, va, cols, x):
         return d_y.copyToHost(len(rp) - 1), spmv.csr_tiled_info(A)
     finally:
         spmv.csr_destroy(A)
+
+
+def test_tiled_engine_is_reproducible_run_to_run_and_across_plan_rebuilds(gpu):
+    """SURVEY §5 / H4 (determinism).  The plan layout is a pure function of the matrix (no global atomics in
+    the build), phase 2 accumulates every row in fp64 in LDS (a sum of fp32 products is then independent of
+    the order in which the wavefronts' adds arrive, as long as the products of a row span < 29 binades), and
+    the long rows' chunk sums are added in chunk order: y must come out bit for bit the same on every run and
+    after a rebuild of the plan — on a uniform matrix and on a power-law one with long rows."""
+    wl = importlib.import_module("gpu-spmv_amd.workloads")
+    for A, kernel in ((wl.uniform_csr_device(5, 600_000, 700_000, 12), 1),
+                      (wl.power_law_csr_device(5, 500_000, 500_000), 2)):
+        x = wl.vector_device(5, 1, A.cols)
+        y = gpu.CudaBuffer(A.rows)
+        cfg = gpu.SpMVConfig(kernel, 256, True)
+        outs = []
+        for rebuild in (False, False, True, False):
+            if rebuild:
+                gpu.csr_invalidate_gpu_cache(A.handle)
+            assert gpu.spmv_csr(A.handle, x, y, cfg, A.cols).error_code == 0
+            assert gpu.csr_has_tiled_plan(A.handle)
+            outs.append(y.copyToHost(A.rows).view(np.uint32).copy())
+        if kernel == 2:
+            assert gpu.csr_tiled_info(A.handle)["long_rows"] > 0
+        for other in outs[1:]:
+            assert np.array_equal(outs[0], other)
+        x.release()
+        y.release()
+        A.close()
 
 
 def test_tiled_engine_folds_column_uniform_values(gpu, oracle, monkeypatch):

@@ -139,23 +139,80 @@ def main():
     exchange = "none" if world == 1 else "gather"
     pr.mode = "gather"
 
-    step = 0
-    for _ in range(args.warmup):
-        pr.iterate(step, damping, never)
-        step += 1
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pr.iterate(step, damping, never)
-        step += 1
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    iters_done = engine.status()[0]
-    assert iters_done == args.warmup + args.steps, (iters_done, args.warmup, args.steps)
+    def timed(loop, its_engine):
+        """W untimed + K timed iterations of `loop`; seconds for the K, max over the ranks."""
+        loop.reset()
+        step = 0
+        for _ in range(args.warmup):
+            loop.iterate(step, damping, never)
+            step += 1
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loop.iterate(step, damping, never)
+            step += 1
+        barrier()
+        seconds = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([seconds], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            seconds = float(t.item())
+        iters_done = its_engine.status()[0]
+        assert iters_done == args.warmup + args.steps, (iters_done, args.warmup, args.steps)
+        return seconds
+
+    elapsed = timed(pr, engine)
+    exchange_trials = None
+
+    # ---- N > 1: the same K steps with the OVERLAPPED exchange (Layout(chunks=C): C all-gathers per step, the
+    # products of block c computed while block c + 1 is on the links; pagerank_dist.py).  Same collectives, same
+    # kernels, another numbering of the vector — so it is first checked against the one-collective run (4 steps
+    # from the start vector, every node within 1e-5 relative on every rank), and the recorded number is whichever
+    # form was faster over the same W + K steps; config.exchange says which.  SPMV_PR_OVERLAP=0 skips it,
+    # SPMV_PR_OVERLAP=<C> sets the number of blocks (default 4).
+    overlap_blocks = int(os.environ.get("SPMV_PR_OVERLAP", "4"))
+    if world > 1 and overlap_blocks > 1:
+        lay2 = prd.Layout(n, world, rank, chunks=overlap_blocks)
+        cols2 = torch.empty_like(cols)
+        scratch_ptrs, scratch_vals = torch.empty_like(row_ptrs), torch.empty_like(vals)
+        status = spmv.lib().spmv_c_gen_uniform_rows(args.seed, row_begin, local_rows, n, k, scratch_ptrs.data_ptr(),
+                                                    cols2.data_ptr(), scratch_vals.data_ptr(), stream)   # the node ids again
+        assert status == 0, spmv.spmv_error_string(status)
+        torch.cuda.synchronize()
+        del scratch_ptrs, scratch_vals
+        cols2_v = cols2[: local_rows * k]
+        cols2_v.copy_(lay2.remap_columns(cols2_v))
+        # (its own copy of the row pointers: the library keys a matrix's cached plan by that array)
+        row_ptrs2 = row_ptrs.clone()
+        engine2 = prd.HipEngine(row_ptrs2, cols2_v, vals_v, lay2)
+        pr2 = prd.ShardedPageRank(engine2, lay2).prepare()
+
+        def after(loop, steps):
+            loop.reset()
+            for i in range(steps):
+                loop.iterate(i, damping, never)
+            torch.cuda.synchronize()
+            return loop.r[steps & 1][loop._pos].clone()
+        ref, got = after(pr, 4), after(pr2, 4)
+        worst = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max())
+        agree = torch.tensor([1 if worst <= 1e-5 else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        del ref, got
+        exchange_trials = {"gather_ms_per_step": round(elapsed / args.steps * 1e3, 4), "overlapped_blocks": overlap_blocks,
+                           "overlapped_max_rel_diff_after_4_steps": worst, "overlapped_agrees": bool(int(agree.item()))}
+        if int(agree.item()) == 1:
+            elapsed2 = timed(pr2, engine2)
+            exchange_trials["overlapped_ms_per_step"] = round(elapsed2 / args.steps * 1e3, 4)
+            if elapsed2 < elapsed:          # the same on every rank (both are all-reduced maxima)
+                engine.close()
+                pr.close()
+                engine, pr, layout, elapsed = engine2, pr2, lay2, elapsed2
+                cols_v = cols2_v
+                exchange = "gather-overlapped x%d" % overlap_blocks
+                engine2 = pr2 = None
+        if engine2 is not None:
+            engine2.close()
+            pr2.close()
 
     bytes_per_step = csr_bytes(n, n, nnz_total)
     ms_per_step = elapsed / args.steps * 1e3
@@ -216,8 +273,9 @@ def main():
                    "plan_note": "one-time per matrix, outside the timed region; break-even against the direct kernel "
                                 "after ~4 SpMVs (pagerank() starts on the direct kernel and builds it after 4 steps)",
                    "parallelism": "row-shard x%d%s" % (world, "" if world == 1 else
-                       " + one RCCL all-gather per step (%d f32/rank, partial sums in the slice tails)" % layout.stride),
-                   "exchange": exchange,
+                       " + %d RCCL all-gather(s) per step (%d f32/rank each, partial sums in the slice tails)"
+                       % (layout.chunks, layout.piece)),
+                   "exchange": exchange, "exchange_trials": exchange_trials,
                    "values_folded": bool(plan_info and plan_info.get("values_folded"))},
         "gflops": round(2.0 * nnz_total * args.steps / elapsed / 1e9, 1),
         "pagerank_iters_per_sec": round(args.steps / elapsed, 2),

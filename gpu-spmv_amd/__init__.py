@@ -201,7 +201,9 @@ _SIGNATURES = {
     "spmv_c_pagerank_multi_gpu": (c_int, [POINTER(CSRMatrix), POINTER(PageRankConfig), c_int, POINTER(_PageRankResultC)]),
     "spmv_c_pagerank_shard_bounds": (c_int, [POINTER(c_int32), c_int, c_int, POINTER(c_int32)]),
     "spmv_c_pr_shard_create": (c_void_p, [POINTER(CSRMatrix), c_int, c_int, c_void_p]),
+    "spmv_c_pr_shard_create_chunked": (c_void_p, [POINTER(CSRMatrix), c_int, c_int, c_int, c_int, c_void_p]),
     "spmv_c_pr_shard_destroy": (None, [c_void_p]),
+    "spmv_c_pr_expand": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "spmv_c_pr_reset": (c_int, [c_void_p, c_float, c_void_p]),
     "spmv_c_pr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "spmv_c_pr_step_push": (c_int, [c_void_p, c_void_p, c_void_p, c_float, POINTER(c_void_p), c_int, c_void_p]),

@@ -33,7 +33,7 @@ void release(CsrAux* a) {
     if (a->d_tile_rows) (void)hipFree(a->d_tile_rows);
     if (a->d_carry_row) (void)hipFree(a->d_carry_row);
     if (a->d_carry_val) (void)hipFree(a->d_carry_val);
-    if (a->tiled) tiled_free(a->tiled);
+    a->tiled.reset();        // (users still holding the plan keep it alive)
     delete a;
 }
 
@@ -119,34 +119,39 @@ std::mutex g_build_lock;   // one plan build at a time (two threads may meet on 
 }
 
 namespace {
-bool plan_matches(const TiledPlan* p, const CSRMatrix* A) {
+bool plan_matches(const std::shared_ptr<TiledPlan>& p, const CSRMatrix* A) {
     return p->num_rows == A->num_rows && p->num_cols == A->num_cols && p->csr_nnz == A->nnz &&
            p->csr_cols == A->d_col_indices && p->csr_vals == A->d_values;
 }
+std::shared_ptr<TiledPlan> adopt(TiledPlan* raw) {
+    return std::shared_ptr<TiledPlan>(raw, [](TiledPlan* p) { tiled_free(p); });
+}
 }
 
-const TiledPlan* tiled_plan_if_cached(const CSRMatrix* A) {
+PlanRef tiled_plan_if_cached(const CSRMatrix* A) {
     if (!A || !A->d_row_ptrs) return nullptr;
     std::lock_guard<std::mutex> building(g_build_lock);
     CsrAux* aux = aux_lookup(A->d_row_ptrs, false);
-    return aux && aux->tiled && plan_matches(aux->tiled, A) ? aux->tiled : nullptr;
+    if (aux && aux->tiled && plan_matches(aux->tiled, A)) return aux->tiled;
+    return nullptr;
 }
 
-const TiledPlan* tiled_plan_for(const CSRMatrix* A, hipStream_t s) {
+PlanRef tiled_plan_for(const CSRMatrix* A, hipStream_t s) {
     if (!A || !A->d_row_ptrs || !tiled_eligible(A)) return nullptr;
     std::lock_guard<std::mutex> building(g_build_lock);
     CsrAux* aux = aux_lookup(A->d_row_ptrs, true);
     if (aux->tiled && !plan_matches(aux->tiled, A)) {
-        tiled_free(aux->tiled);       // header or arrays changed under the same row-pointer array
-        aux->tiled = nullptr;
+        aux->tiled.reset();           // header or arrays changed under the same row-pointer array
         aux->tiled_failed = false;
     }
     if (!aux->tiled && !aux->tiled_failed) {
         const TraceRange range("spmv:tiled_plan_build");
-        if (tiled_build(A, &aux->tiled, s) != hipSuccess) {
+        TiledPlan* built = nullptr;
+        if (tiled_build(A, &built, s) != hipSuccess) {
             (void)hipGetLastError();
-            aux->tiled = nullptr;
             aux->tiled_failed = true;
+        } else {
+            aux->tiled = adopt(built);
         }
     }
     return aux->tiled;
@@ -170,27 +175,27 @@ void ell_aux_drop(const void* key) {
     auto& t = ell_table();
     auto it = t.find(key);
     if (it == t.end()) return;
-    if (it->second->tiled) tiled_free(it->second->tiled);
     delete it->second;
     t.erase(it);
 }
 
-const TiledPlan* tiled_plan_for(const ELLMatrix* A, hipStream_t s) {
+PlanRef tiled_plan_for(const ELLMatrix* A, hipStream_t s) {
     if (!A || !A->d_col_indices || !A->d_values || !tiled_eligible(A)) return nullptr;
     std::lock_guard<std::mutex> building(g_build_lock);
     EllAux* aux = ell_aux_lookup(A->d_col_indices, true);
     if (aux->tiled && (aux->tiled->num_rows != A->num_rows || aux->tiled->num_cols != A->num_cols ||
                        aux->tiled->csr_nnz != static_cast<long long>(A->num_rows) * A->max_nnz_per_row ||
                        aux->tiled->csr_vals != A->d_values)) {
-        tiled_free(aux->tiled);
-        aux->tiled = nullptr;
+        aux->tiled.reset();
         aux->tiled_failed = false;
     }
     if (!aux->tiled && !aux->tiled_failed) {
-        if (tiled_build(A, &aux->tiled, s) != hipSuccess) {
+        TiledPlan* built = nullptr;
+        if (tiled_build(A, &built, s) != hipSuccess) {
             (void)hipGetLastError();
-            aux->tiled = nullptr;
             aux->tiled_failed = true;
+        } else {
+            aux->tiled = adopt(built);
         }
     }
     return aux->tiled;

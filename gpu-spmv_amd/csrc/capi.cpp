@@ -399,19 +399,35 @@ void spmv_c_pagerank_top_k(const spmv_c_pagerank_result* result, int num_nodes, 
 // ---- PageRank shard engine ----
 spmv_c_pr_shard* spmv_c_pr_shard_create(const spmv_c_csr* A_local, int row_offset, int n_global,
                                         const uint8_t* d_dangling_mask) {
+    return spmv_c_pr_shard_create_chunked(A_local, row_offset, 0x7fffffff, 0, n_global, d_dangling_mask);
+}
+
+spmv_c_pr_shard* spmv_c_pr_shard_create_chunked(const spmv_c_csr* A_local, int base, int piece, int block,
+                                                int n_global, const uint8_t* d_dangling_mask) {
     const CSRMatrix* A = cxx(A_local);
     // the rank vector is indexed by column (num_cols long, possibly padded); n_global is the true node count
-    if (!A || row_offset < 0 || n_global <= 0 || !d_dangling_mask || n_global > A->num_cols ||
-        static_cast<long long>(row_offset) + A->num_rows > A->num_cols ||
+    if (!A || base < 0 || piece <= 0 || block < 0 || n_global <= 0 || !d_dangling_mask || n_global > A->num_cols ||
         (A->num_rows > 0 && !A->d_row_ptrs) ||
         (A->nnz > 0 && (!A->d_col_indices || !A->d_values))) {
         return nullptr;
+    }
+    detail::RowMap map;
+    map.base = base;
+    map.piece = piece;
+    map.block = block;
+    // every local row must land inside the vector, pieces must not overlap
+    if (A->num_rows > 0) {
+        const bool chunked = piece != 0x7fffffff;
+        if (chunked && block < piece) return nullptr;
+        const long long pieces = chunked ? (static_cast<long long>(A->num_rows) + piece - 1) / piece : 1;
+        const long long last = map.at(static_cast<long long>(A->num_rows) - 1);
+        if (last >= A->num_cols || (pieces > 1 && static_cast<long long>(base) + piece > block)) return nullptr;
     }
     spmv_c_pr_shard* h = new (std::nothrow) spmv_c_pr_shard();
     if (!h) return nullptr;
     detail::PrShard& sh = h->shard;
     sh.local_rows = A->num_rows;
-    sh.row_offset = row_offset;
+    sh.map = map;
     sh.n_global = n_global;
     sh.nnz = A->nnz;
     sh.d_row_ptrs = A->d_row_ptrs;
@@ -439,6 +455,8 @@ int spmv_c_pr_reset(spmv_c_pr_shard* h, float dangling_sum, void* hip_stream) {
     if (!h) return kInvalidArgument;
     detail::PrState fresh{};
     fresh.dangling_sum = dangling_sum;
+    h->shard.expanded_strips = 0;          // a head start taken for a step that never ran is void
+    h->shard.expanded_long = false;
     // pageable source: the copy is staged before the call returns
     return hipMemcpyAsync(h->shard.d_state, &fresh, sizeof(fresh), hipMemcpyHostToDevice,
                           as_stream(hip_stream)) == hipSuccess
@@ -450,6 +468,11 @@ int spmv_c_pr_step(spmv_c_pr_shard* h, const float* d_r_old, float* d_r_new, flo
     if (!h || !d_r_old || !d_r_new) return kInvalidArgument;
     return launch_code(detail::pr_step(h->shard, d_r_old, d_r_new, damping, detail::PushTargets{},
                                        as_stream(hip_stream)));
+}
+
+int spmv_c_pr_expand(spmv_c_pr_shard* h, const float* d_r_old, int64_t cols_ready, void* hip_stream) {
+    if (!h || !d_r_old) return kInvalidArgument;
+    return launch_code(detail::pr_expand(h->shard, d_r_old, cols_ready, as_stream(hip_stream)));
 }
 
 int spmv_c_pr_step_push(spmv_c_pr_shard* h, const float* d_r_old, float* d_r_new, float damping,

@@ -9,6 +9,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 
 namespace spmv {
 namespace detail {
@@ -19,6 +20,9 @@ inline int code(SpMVError e) { return static_cast<int>(e); }
 // The public structs cannot grow (callers poke the fields), so anything the
 // kernels precompute for a matrix lives here and is dropped by csr_free_gpu.
 struct TiledPlan;
+// A plan is shared between the side table and whoever is using it (a dispatch in flight, a PageRank shard
+// engine): replacing or dropping the table's entry never pulls it from under a user.
+using PlanRef = std::shared_ptr<const TiledPlan>;
 
 // Buffers of pagerank() kept with the matrix between calls (seven device allocations, a pinned mirror and
 // two events per call cost more than the iterations on a large graph), plus the dangling mask, which
@@ -54,14 +58,14 @@ struct CsrAux {
     int*   d_carry_row = nullptr;    // [num_tiles]
     float* d_carry_val = nullptr;    // [num_tiles]
     // LDS-tiled engine: bucketed copy of the entries, built on first use (tiled.h)
-    TiledPlan* tiled = nullptr;
+    std::shared_ptr<TiledPlan> tiled;
     bool tiled_failed = false;       // build failed once (e.g. out of memory): do not retry
 };
 
 // the matrix's tiled plan (built on first call), or nullptr when not eligible / not buildable
-const TiledPlan* tiled_plan_for(const CSRMatrix* A, hipStream_t s);
+PlanRef tiled_plan_for(const CSRMatrix* A, hipStream_t s);
 // the plan only if the matrix already holds a valid one (never builds)
-const TiledPlan* tiled_plan_if_cached(const CSRMatrix* A);
+PlanRef tiled_plan_if_cached(const CSRMatrix* A);
 
 CsrAux* aux_lookup(const void* key, bool create);
 void    aux_drop(const void* key);
@@ -69,10 +73,10 @@ void    aux_drop(const void* key);
 struct EllAux {
     bool have_nnz = false;
     long long actual_nnz = 0;   // non-padding slots, counted once on the device
-    TiledPlan* tiled = nullptr; // LDS-tiled engine plan built from the slabs (use_texture)
+    std::shared_ptr<TiledPlan> tiled; // LDS-tiled engine plan built from the slabs (use_texture)
     bool tiled_failed = false;
 };
-const TiledPlan* tiled_plan_for(const ELLMatrix* A, hipStream_t s);
+PlanRef tiled_plan_for(const ELLMatrix* A, hipStream_t s);
 EllAux* ell_aux_lookup(const void* key, bool create);
 void    ell_aux_drop(const void* key);
 

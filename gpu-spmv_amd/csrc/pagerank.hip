@@ -14,7 +14,7 @@
 // convergence check without changing the result.
 //
 // The same kernels serve the row-sharded multi-GPU loop (pr_* entry points):
-// each rank owns rows [row_offset, row_offset + local_rows) of A and a
+// each rank owns local_rows consecutive rows of A (their nodes placed by a RowMap) and a
 // full-length rank vector; the host all-reduces the two partial sums and
 // all-gathers the new slice (RCCL) between `pr_reduce` and `pr_commit`.
 #include "internal.h"
@@ -44,7 +44,7 @@ using namespace dev;
 // One power-iteration step over this shard's rows.
 template <int LANES>
 __global__ __launch_bounds__(kBlock)
-void pr_step_kernel(int local_rows, int row_offset, int n_global, long long nnz,
+void pr_step_kernel(int local_rows, RowMap map, int n_global, long long nnz,
                     const int* __restrict__ row_ptrs,
                     const int* __restrict__ cols,
                     const float* __restrict__ vals,
@@ -76,7 +76,7 @@ void pr_step_kernel(int local_rows, int row_offset, int n_global, long long nnz,
         }
         acc = group_sum<LANES>(acc);
         if (lane == 0 && row < local_rows) {
-            const long long node = row_offset + row;
+            const long long node = map.at(row);
             const float fresh = __fadd_rn(__fadd_rn(__fmul_rn(damping, acc), dangling_term), teleport);
             r_new[node] = fresh;
             for (int p = 0; p < push.count; ++p) push.ptr[p][node] = fresh;
@@ -286,7 +286,7 @@ template <int LANES>
 hipError_t launch_step(const PrShard& sh, const float* r_old, float* r_new, float damping,
                        const PushTargets& push, hipStream_t s) {
     pr_step_kernel<LANES><<<sh.grid, kBlock, 0, s>>>(
-        sh.local_rows, sh.row_offset, sh.n_global, sh.nnz, sh.d_row_ptrs, sh.d_cols, sh.d_vals,
+        sh.local_rows, sh.map, sh.n_global, sh.nnz, sh.d_row_ptrs, sh.d_cols, sh.d_vals,
         r_old, r_new, sh.d_dangling, damping, sh.d_state, sh.d_block_partials, push);
     return hipGetLastError();
 }
@@ -295,11 +295,11 @@ hipError_t launch_step(const PrShard& sh, const float* r_old, float* r_new, floa
 
 int pr_max_blocks() { return kMaxResidentBlocks; }
 
-int pr_shard_prepare(PrShard* sh, const TiledPlan* tiled) {
+int pr_shard_prepare(PrShard* sh, PlanRef tiled) {
     const float avg = sh->local_rows > 0 ? static_cast<float>(sh->nnz) / sh->local_rows : 0.0f;
     sh->lanes = pick_lanes_per_row(avg);
-    sh->tiled = tiled;
-    sh->grid = tiled ? tiled->num_tiles : grid_for(sh->local_rows, kBlock / sh->lanes);
+    sh->tiled = std::move(tiled);
+    sh->grid = sh->tiled ? sh->tiled->num_tiles : grid_for(sh->local_rows, kBlock / sh->lanes);
     return std::max(sh->grid, kMaxResidentBlocks);
 }
 
@@ -307,8 +307,17 @@ hipError_t pr_step(const PrShard& sh, const float* r_old, float* r_new, float da
                    const PushTargets& push, hipStream_t s) {
     if (sh.local_rows <= 0) return hipSuccess;
     if (sh.tiled) {
-        return tiled_pagerank_step(*sh.tiled, sh.row_offset, sh.n_global, r_old, r_new, sh.d_dangling,
-                                   damping, sh.d_state, sh.d_block_partials, push, s);
+        // phase 1 of whatever pr_expand has not run yet (all of it, normally), then phase 2
+        const int done = std::min(sh.expanded_strips, sh.tiled->num_strips);
+        const bool long_done = sh.expanded_long;
+        sh.expanded_strips = 0;
+        sh.expanded_long = false;
+        if (done < sh.tiled->num_strips || !long_done) {
+            const hipError_t e = tiled_pagerank_expand(*sh.tiled, done, sh.tiled->num_strips, !long_done, r_old, sh.d_state, s);
+            if (e != hipSuccess) return e;
+        }
+        return tiled_pagerank_finish(*sh.tiled, sh.map, sh.n_global, r_old, r_new, sh.d_dangling,
+                                     damping, sh.d_state, sh.d_block_partials, push, s);
     }
     switch (sh.lanes) {
         case 1:  return launch_step<1>(sh, r_old, r_new, damping, push, s);
@@ -319,6 +328,22 @@ hipError_t pr_step(const PrShard& sh, const float* r_old, float* r_new, float da
         case 32: return launch_step<32>(sh, r_old, r_new, damping, push, s);
         default: return launch_step<64>(sh, r_old, r_new, damping, push, s);
     }
+}
+
+hipError_t pr_expand(const PrShard& sh, const float* r_old, long long cols_ready, hipStream_t s) {
+    if (sh.local_rows <= 0 || !sh.tiled) return hipSuccess;
+    const TiledPlan& plan = *sh.tiled;
+    const bool all = cols_ready >= plan.num_cols;
+    const int ready = all ? plan.num_strips : static_cast<int>(std::max(0LL, cols_ready) / plan.strip_cols);
+    const int done = std::min(sh.expanded_strips, plan.num_strips);
+    const bool want_long = all && !sh.expanded_long;       // the long rows read all of r_old
+    if (ready <= done && !want_long) return hipSuccess;
+    const hipError_t e = tiled_pagerank_expand(plan, done, std::max(ready, done), want_long, r_old, sh.d_state, s);
+    if (e == hipSuccess) {
+        sh.expanded_strips = std::max(ready, done);
+        sh.expanded_long = sh.expanded_long || want_long;
+    }
+    return e;
 }
 
 hipError_t pr_reduce(const PrShard& sh, double* d_sums, hipStream_t s) {
@@ -595,7 +620,7 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     // first step; otherwise the loop starts on the direct kernel and builds the plan only once it has
     // spent about one build's worth of time on direct steps (ski rental: never more than ~2x the better
     // choice).  Estimates per stored entry, measured on C5: build 50 ps, direct step 17 ps, tiled step 3.3 ps.
-    const detail::TiledPlan* plan = detail::tiled_plan_if_cached(adj);
+    detail::PlanRef plan = detail::tiled_plan_if_cached(adj);
     int build_plan_at = -1;
     if (!plan && detail::tiled_eligible(adj)) {
         build_plan_at = static_cast<int>(std::ceil(50.0 / (17.0 - 3.3)));            // = 4 direct steps
@@ -607,7 +632,6 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     const size_t len = static_cast<size_t>(std::max(n, adj->num_cols));
     detail::PrShard shard;
     shard.local_rows = n;
-    shard.row_offset = 0;
     shard.n_global = n;
     shard.nnz = adj->nnz;
     shard.d_row_ptrs = adj->d_row_ptrs;

@@ -227,7 +227,7 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
         d.have_header = true;
         detail::PrShard& sh = d.shard;
         sh.local_rows = rows;
-        sh.row_offset = static_cast<int>(p * stride);
+        sh.map.base = static_cast<int>(p * stride);
         sh.n_global = n;
         sh.nnz = local_nnz;
         sh.d_row_ptrs = d.d_row_ptrs;

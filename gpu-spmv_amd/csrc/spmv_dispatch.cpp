@@ -67,7 +67,7 @@ hipError_t enqueue_csr(const CSRMatrix* A, const float* d_x, float* d_y,
     // CPU-order contract and never takes this route.
     if (config->use_texture && (config->kernel_type == SpMVConfig::VECTOR_CSR ||
                                 config->kernel_type == SpMVConfig::MERGE_PATH)) {
-        if (const TiledPlan* plan = tiled_plan_for(A, stream)) {
+        if (const PlanRef plan = tiled_plan_for(A, stream)) {
             return tiled_spmv(*plan, d_x, d_y, stream);
         }
     }
@@ -121,7 +121,7 @@ hipError_t enqueue_ell(const ELLMatrix* A, const float* d_x, float* d_y, const S
     if (A->max_nnz_per_row == 0) return launch_fill_zero(d_y, A->num_rows, stream);
     // use_texture: x through LDS tiles (gives up the default kernel's CPU summation order)
     if (config->use_texture) {
-        if (const TiledPlan* plan = tiled_plan_for(A, stream)) return tiled_spmv(*plan, d_x, d_y, stream);
+        if (const PlanRef plan = tiled_plan_for(A, stream)) return tiled_spmv(*plan, d_x, d_y, stream);
     }
     return launch_ell(A, d_x, d_y, stream);
 }

@@ -13,6 +13,7 @@ namespace detail {
 
 struct PrState;
 struct PushTargets;
+struct RowMap;
 
 // Per-matrix bucketed copy of the entries (built once on the device, cached in the
 // side table, dropped by csr_free_gpu).
@@ -37,6 +38,7 @@ struct TiledPlan {
     // phase-1 work items: (strip, begin, end), at most kItemEntries slots each
     int* items = nullptr;           // [3 * num_items]
     int  num_items = 0;
+    int* strip_first_item = nullptr; // HOST [num_strips + 1]: the items are sorted by strip
 
     // rows longer than long_row: summed by one wavefront per 512-entry chunk from the CSR arrays
     int*   long_rows = nullptr;     // [num_long] ascending
@@ -73,14 +75,19 @@ void tiled_free(TiledPlan* plan);
 // y = A x
 hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipStream_t s);
 
-// PageRank step on the same plan: r_new[row_offset + i] = d * (A r_old)_i + d*s/n + (1-d)/n,
-// block partial sums of (r_new - r_old)^2 and of r_new over dangling nodes -> block_partials
-// [2 * plan.num_tiles]; no-op when state->done.
-hipError_t tiled_pagerank_step(const TiledPlan& plan, int row_offset, int n_global,
-                               const float* d_r_old, float* d_r_new,
-                               const unsigned char* d_dangling, float damping,
-                               const PrState* d_state, double* d_block_partials,
-                               const PushTargets& push, hipStream_t s);
+// PageRank step on the same plan, in two parts.
+// Phase 1 for the strips [strip_begin, strip_end) — products of the entries whose columns lie there — and,
+// with_long, the long rows (which read all of r_old).  A step needs every strip and the long rows exactly
+// once, in any number of calls, before its finish.  No-op when state->done.
+hipError_t tiled_pagerank_expand(const TiledPlan& plan, int strip_begin, int strip_end, bool with_long,
+                                 const float* d_r_old, const PrState* d_state, hipStream_t s);
+// Phase 2: r_new[map.at(i)] = d * (A r_old)_i + d*s/n + (1-d)/n, block partial sums of (r_new - r_old)^2
+// and of r_new over dangling nodes -> block_partials [2 * plan.num_tiles]; no-op when state->done.
+hipError_t tiled_pagerank_finish(const TiledPlan& plan, const RowMap& map, int n_global,
+                                 const float* d_r_old, float* d_r_new,
+                                 const unsigned char* d_dangling, float damping,
+                                 const PrState* d_state, double* d_block_partials,
+                                 const PushTargets& push, hipStream_t s);
 
 } // namespace detail
 } // namespace spmv

@@ -818,7 +818,7 @@ __device__ __forceinline__ void long_row_chunk(const LongRows& lr, int which, co
 // as w_j * x_j and an entry's product is a plain LDS read (the same rounded product as a_ij * x_j).
 template <int W, int kExpandBlock, bool FOLD>
 __global__ __launch_bounds__(kExpandBlock)
-void tiled_expand_kernel(const int* __restrict__ items, int num_items, int long_blocks,
+void tiled_expand_kernel(const int* __restrict__ items, int first_item, int num_items, int long_blocks,
                          const float* __restrict__ a_val,
                          const unsigned short* __restrict__ a_lcol,
                          const float* __restrict__ col_weight,
@@ -833,8 +833,9 @@ void tiled_expand_kernel(const int* __restrict__ items, int num_items, int long_
         return;
     }
     __shared__ float xs[W];
-    const int item = xcd_contiguous(blockIdx.x - long_blocks, num_items);     // long_blocks is a multiple of 8
-    if (item < 0) return;
+    const int window = xcd_contiguous(blockIdx.x - long_blocks, num_items);   // long_blocks is a multiple of 8
+    if (window < 0) return;
+    const int item = first_item + window;
     const int strip = items[3 * item];
     const int begin = items[3 * item + 1];
     const int end = items[3 * item + 2];
@@ -915,18 +916,6 @@ void tiled_expand_kernel(const int* __restrict__ items, int num_items, int long_
 }
 
 // ------------------------------------------------------------------------ phase 2 ----
-// float add on an LDS word by compare-and-swap on its integer image
-__device__ __forceinline__ void lds_add(float* slot, float v) {
-    unsigned int* word = reinterpret_cast<unsigned int*>(slot);
-    unsigned int seen = *word;
-    for (;;) {
-        const unsigned int want = __float_as_uint(__uint_as_float(seen) + v);
-        const unsigned int got = atomicCAS(word, seen, want);
-        if (got == seen) break;
-        seen = got;
-    }
-}
-
 // inclusive prefix sum over the 64 lanes of a wavefront: Hillis-Steele inside each 16-lane DPP row
 // (row_shr 1, 2, 4, 8; lanes shifted in from outside the row contribute 0), then the classic wave64 tail:
 // row_bcast:15 adds lane 15 of the previous row into rows 1 and 3, row_bcast:31 adds lane 31 into rows 2, 3
@@ -1133,7 +1122,7 @@ void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__
                                   const float* __restrict__ prod,
                                   const unsigned char* __restrict__ a_drow,
                                   const LongSeeds seeds,
-                                  int local_rows, int row_offset, int n_global,
+                                  int local_rows, RowMap map, int n_global,
                                   const float* __restrict__ r_old, float* __restrict__ r_new,
                                   const unsigned char* __restrict__ dangling, float damping,
                                   const PrState* __restrict__ state,
@@ -1150,7 +1139,7 @@ void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__
     double res2 = 0.0, mass = 0.0;
     const long long first = static_cast<long long>(tile_index) * R;
     for (int i = threadIdx.x; i < R && first + i < local_rows; i += kReduceBlock) {
-        const long long node = row_offset + first + i;
+        const long long node = map.at(first + i);
         const float fresh = __fadd_rn(__fadd_rn(__fmul_rn(damping, static_cast<float>(tile[i])), dangling_term), teleport);
         r_new[node] = fresh;
         for (int p = 0; p < push.count; ++p) push.ptr[p][node] = fresh;     // straight into the peers' vectors
@@ -1217,28 +1206,32 @@ void choose_shape(long long num_rows, long long num_cols, long long nnz, int* st
     *tile_rows = r;
 }
 
+// phase 1 for the items [first_item, first_item + num_items) and, with_long, the long-row chunks
 template <int W, int BLOCK>
-hipError_t launch_expand_as(const TiledPlan& plan, const float* d_x, const PrState* d_state, hipStream_t s) {
-    const LongRows lr{plan.long_chunks, plan.num_long_chunks, plan.csr_nnz, plan.csr_cols, plan.csr_vals, plan.long_sums};
-    const int long_blocks = xcd_grid((plan.num_long_chunks + BLOCK / 64 - 1) / (BLOCK / 64));
-    const int grid = long_blocks + xcd_grid(plan.num_items);
+hipError_t launch_expand_as(const TiledPlan& plan, int first_item, int num_items, bool with_long, const float* d_x,
+                            const PrState* d_state, hipStream_t s) {
+    const int chunks = with_long ? plan.num_long_chunks : 0;
+    const LongRows lr{plan.long_chunks, chunks, plan.csr_nnz, plan.csr_cols, plan.csr_vals, plan.long_sums};
+    const int long_blocks = xcd_grid((chunks + BLOCK / 64 - 1) / (BLOCK / 64));
+    const int grid = long_blocks + xcd_grid(num_items);
+    if (grid == 0) return hipSuccess;
     if (plan.col_weight) {
         tiled_expand_kernel<W, BLOCK, true><<<grid, BLOCK, 0, s>>>(
-            plan.items, plan.num_items, long_blocks, nullptr, plan.a_lcol, plan.col_weight, d_x, plan.num_cols, plan.prod, lr, d_state);
+            plan.items, first_item, num_items, long_blocks, nullptr, plan.a_lcol, plan.col_weight, d_x, plan.num_cols, plan.prod, lr, d_state);
     } else {
         tiled_expand_kernel<W, BLOCK, false><<<grid, BLOCK, 0, s>>>(
-            plan.items, plan.num_items, long_blocks, plan.a_val, plan.a_lcol, nullptr, d_x, plan.num_cols, plan.prod, lr, d_state);
+            plan.items, first_item, num_items, long_blocks, plan.a_val, plan.a_lcol, nullptr, d_x, plan.num_cols, plan.prod, lr, d_state);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_expand(const TiledPlan& plan, const float* d_x, const PrState* d_state, hipStream_t s) {
-    if (plan.num_items == 0 && plan.num_long_chunks == 0) return hipSuccess;
+hipError_t launch_expand(const TiledPlan& plan, int first_item, int num_items, bool with_long, const float* d_x,
+                         const PrState* d_state, hipStream_t s) {
     switch (plan.strip_cols) {
-        case 4096:  return launch_expand_as<4096, 512>(plan, d_x, d_state, s);
-        case 8192:  return launch_expand_as<8192, 512>(plan, d_x, d_state, s);
-        case 16384: return launch_expand_as<16384, 512>(plan, d_x, d_state, s);
-        default:    return launch_expand_as<32768, 1024>(plan, d_x, d_state, s);   // 128 KiB of LDS: one workgroup per CU
+        case 4096:  return launch_expand_as<4096, 512>(plan, first_item, num_items, with_long, d_x, d_state, s);
+        case 8192:  return launch_expand_as<8192, 512>(plan, first_item, num_items, with_long, d_x, d_state, s);
+        case 16384: return launch_expand_as<16384, 512>(plan, first_item, num_items, with_long, d_x, d_state, s);
+        default:    return launch_expand_as<32768, 1024>(plan, first_item, num_items, with_long, d_x, d_state, s);   // 128 KiB of LDS: one workgroup per CU
     }
 }
 
@@ -1267,7 +1260,7 @@ hipError_t launch_reduce(const TiledPlan& plan, float* d_y, hipStream_t s) {
 }
 
 template <int BLOCK, int E, int kRuns>
-hipError_t launch_pagerank_reduce_as(const TiledPlan& plan, int row_offset, int n_global, const float* d_r_old,
+hipError_t launch_pagerank_reduce_as(const TiledPlan& plan, const RowMap& map, int n_global, const float* d_r_old,
                                      float* d_r_new, const unsigned char* d_dangling, float damping,
                                      const PrState* d_state, double* d_block_partials,
                                      const PushTargets& push, hipStream_t s) {
@@ -1277,17 +1270,17 @@ hipError_t launch_pagerank_reduce_as(const TiledPlan& plan, int row_offset, int 
     if (e != hipSuccess) return e;
     tiled_pagerank_reduce_kernel<BLOCK, E, kRuns><<<xcd_grid(plan.num_tiles), BLOCK, lds, s>>>(
         plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_drow,
-        long_seeds(plan), plan.num_rows, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
+        long_seeds(plan), plan.num_rows, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
         d_block_partials, push);
     return hipGetLastError();
 }
 
-hipError_t launch_pagerank_reduce(const TiledPlan& plan, int row_offset, int n_global, const float* d_r_old,
+hipError_t launch_pagerank_reduce(const TiledPlan& plan, const RowMap& map, int n_global, const float* d_r_old,
                                   float* d_r_new, const unsigned char* d_dangling, float damping,
                                   const PrState* d_state, double* d_block_partials,
                                   const PushTargets& push, hipStream_t s) {
 #define SPMV_PR_REDUCE(BLOCK, E, RUNS) \
-    launch_pagerank_reduce_as<BLOCK, E, RUNS>(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state, \
+    launch_pagerank_reduce_as<BLOCK, E, RUNS>(plan, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state, \
                                               d_block_partials, push, s)
     switch (plan.lane_entries) {
         case 2:  return SPMV_PR_REDUCE(1024, 2, 4);
@@ -1374,6 +1367,7 @@ void tiled_free(TiledPlan* p) {
     void* owned[] = {p->a_val, p->a_lcol, p->a_drow, p->prod, p->cells_t, p->items, p->long_rows, p->long_chunks,
                      p->long_first, p->long_sums, p->tile_long, p->col_weight};
     for (void* q : owned) if (q) (void)hipFree(q);
+    delete[] p->strip_first_item;
     delete p;
 }
 
@@ -1692,7 +1686,9 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         kMaxItemEntries, std::max<long long>(floor_entries, (plan->nnz / 2048 + 7) / 8 * 8)));
     if (const char* env = std::getenv("SPMV_TILED_ITEM")) item_entries = std::max(1024, std::atoi(env));
     std::vector<int> items;
+    plan->strip_first_item = new int[static_cast<size_t>(plan->num_strips) + 1];
     for (int strip = 0; strip < plan->num_strips; ++strip) {
+        plan->strip_first_item[strip] = static_cast<int>(items.size() / 3);
         const int begin = host_strip[strip], stop = host_strip[strip + 1];
         const int parts = (stop - begin + item_entries - 1) / item_entries;
         int b = begin;
@@ -1708,6 +1704,7 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         }
     }
     plan->num_items = static_cast<int>(items.size() / 3);
+    plan->strip_first_item[plan->num_strips] = plan->num_items;
     e = dev_alloc(&plan->items, static_cast<long long>(items.size()));
     if (e == hipSuccess && !items.empty()) {
         e = hipMemcpy(plan->items, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice);
@@ -1725,21 +1722,27 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
 } // namespace
 
 hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipStream_t s) {
-    const hipError_t e = launch_expand(plan, d_x, nullptr, s);       // phase 1 + the long rows
+    const hipError_t e = launch_expand(plan, 0, plan.num_items, true, d_x, nullptr, s);       // phase 1 + the long rows
     if (e != hipSuccess) return e;
     return launch_reduce(plan, d_y, s);
 }
 
-hipError_t tiled_pagerank_step(const TiledPlan& plan, int row_offset, int n_global,
-                               const float* d_r_old, float* d_r_new,
-                               const unsigned char* d_dangling, float damping,
-                               const PrState* d_state, double* d_block_partials,
-                               const PushTargets& push, hipStream_t s) {
-    // After convergence both kernels return at once: r_new and the product stream stay as the last committed
-    // step left them.
-    const hipError_t e = launch_expand(plan, d_r_old, d_state, s);   // phase 1 + the long rows (no-op once done)
-    if (e != hipSuccess) return e;
-    return launch_pagerank_reduce(plan, row_offset, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
+// After convergence the kernels of both parts return at once: r_new and the product stream stay as the last
+// committed step left them.
+hipError_t tiled_pagerank_expand(const TiledPlan& plan, int strip_begin, int strip_end, bool with_long,
+                                 const float* d_r_old, const PrState* d_state, hipStream_t s) {
+    strip_begin = std::max(0, std::min(strip_begin, plan.num_strips));
+    strip_end = std::max(strip_begin, std::min(strip_end, plan.num_strips));
+    const int first = plan.strip_first_item[strip_begin];
+    return launch_expand(plan, first, plan.strip_first_item[strip_end] - first, with_long, d_r_old, d_state, s);
+}
+
+hipError_t tiled_pagerank_finish(const TiledPlan& plan, const RowMap& map, int n_global,
+                                 const float* d_r_old, float* d_r_new,
+                                 const unsigned char* d_dangling, float damping,
+                                 const PrState* d_state, double* d_block_partials,
+                                 const PushTargets& push, hipStream_t s) {
+    return launch_pagerank_reduce(plan, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
                                   d_block_partials, push, s);
 }
 

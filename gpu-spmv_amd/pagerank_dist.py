@@ -21,6 +21,12 @@ with stride = shard_len + 4; the shard's column indices are remapped to that lay
 (`Layout.remap_columns`), which costs nothing per iteration.  With world == 1 there is no
 padding, no collective, and commit() consumes the local sums directly.
 
+Overlapped form (Layout(chunks=C), C > 1; SURVEY.md H3 "multiply what has arrived while the rest is in
+flight"): the vector is laid out as C blocks, block c = piece c of every rank, and the exchange is C in-place
+all-gathers issued back to back on a side stream; as soon as block c is complete the tiled engine's phase 1
+runs for the strips inside it (engine.expand), so only the last block's multiply and phase 2 are exposed.
+Same arithmetic, same bits as the one-collective form.
+
 Optional "push" mode (enable_push): the step kernels store every new value straight into the
 peers' vectors as well (IPC-mapped buffers; xGMI is point-to-point, so all 7 links carry
 traffic at once, under the step's own epilogue).  What remains per iteration is a 16-byte
@@ -52,17 +58,26 @@ class Layout:
     (ceil(n / world), what a uniform matrix wants).  `bounds` (world + 1 ascending row indices, e.g. from
     `equal_nnz_bounds`) cuts the rows anywhere — SURVEY.md §8(e): "boundaries chosen by binary search
     on row_ptrs for equal nnz" — so that a power-law graph does not leave one rank with most of the
-    entries.  Every slice of the padded vector has the same stride (the all-gather needs equal counts):
-    stride = longest block (rounded up to even) + TAIL."""
+    entries.
 
-    def __init__(self, n: int, world: int = 1, rank: int = 0, bounds=None):
+    The vector is a sequence of `chunks` BLOCKS; block c holds piece c (`piece` floats) of every rank,
+    back to back, so one in-place all-gather per block delivers it:
+
+        position of rank p's local row i = (i // piece) * block + p * piece + i % piece,   block = world * piece
+
+    chunks == 1 (default): one block, piece = stride = the longest row block (rounded up to even) + TAIL — every
+    rank's slice is contiguous and ONE all-gather per iteration moves everything.  chunks > 1: the overlapped
+    exchange — the all-gather of block c + 1 runs while the products of the columns in block c are computed;
+    pieces are rounded up to `align` columns so that block boundaries are strip boundaries of the tiled engine.
+    The last TAIL floats of a rank's last piece carry its two partial sums (as doubles) in either form."""
+
+    def __init__(self, n: int, world: int = 1, rank: int = 0, bounds=None, chunks: int = 1, align: int = None):
         self.n, self.world, self.rank = n, world, rank
         if bounds is None:
             shard_len = (n + world - 1) // world
             if world > 1 and shard_len % 2:
                 shard_len += 1                      # keeps every tail 8-byte aligned
             self.bounds = np.minimum(np.arange(world + 1, dtype=np.int64) * shard_len, n)
-            self.equal_rows = True
         else:
             self.bounds = np.asarray(bounds, dtype=np.int64)
             assert self.bounds.shape == (world + 1,) and self.bounds[0] == 0 and self.bounds[-1] == n
@@ -70,14 +85,24 @@ class Layout:
             shard_len = int(np.diff(self.bounds).max()) if world > 0 else n
             if world > 1 and shard_len % 2:
                 shard_len += 1
-            self.equal_rows = False
-        self.shard_len = shard_len
-        self.stride = shard_len + (TAIL if world > 1 else 0)
-        self.padded = self.stride * world
+        tail = TAIL if world > 1 else 0
+        self.chunks = max(1, int(chunks)) if world > 1 else 1
+        if self.chunks == 1:
+            self.piece = shard_len + tail
+        else:
+            if align is None:                   # the tiled engine's widest strip, where it can be in play at all
+                align = 32768 if shard_len >= (1 << 18) else 4
+            assert align >= 2 and align % 2 == 0
+            per_chunk = (shard_len + tail + self.chunks - 1) // self.chunks
+            self.piece = (per_chunk + align - 1) // align * align
+        self.block = self.piece * world
+        self.padded = self.block * self.chunks
+        self.shard_len = self.piece * self.chunks - tail     # rows a rank's pieces can hold
+        self.stride = self.piece                               # distance between two ranks' pieces inside a block
         self.row_begin = int(self.bounds[rank])
         self.row_end = int(self.bounds[rank + 1])
         self.local_rows = self.row_end - self.row_begin
-        self.row_offset = rank * self.stride    # position of this rank's first node in the vector
+        self.row_offset = rank * self.piece     # position of this rank's first node in the vector
 
     @staticmethod
     def equal_nnz_bounds(row_ptrs, world: int) -> np.ndarray:
@@ -100,17 +125,21 @@ class Layout:
             return torch.bucketize(nodes, edges, right=True)
         return np.searchsorted(self.bounds[1:-1], nodes, side="right")
 
+    def _place(self, owner, local):
+        """(owning rank, row inside its block of rows) -> position; numpy or torch, elementwise."""
+        if self.chunks == 1:
+            return owner * self.piece + local
+        return (local // self.piece) * self.block + owner * self.piece + local % self.piece
+
     def remap_columns(self, cols):
         """Column (= node) indices -> positions in the padded vector (numpy or torch int32)."""
         if self.world == 1:
             return cols
-        if self.equal_rows:
-            return cols + (cols // self.shard_len) * TAIL
         owner = self.owner_of(cols)
         if isinstance(cols, torch.Tensor):
             begin = torch.as_tensor(self.bounds[:-1], dtype=cols.dtype, device=cols.device)[owner]
-            return (owner * self.stride).to(cols.dtype) + (cols - begin)
-        return (owner * self.stride + (cols - self.bounds[:-1][owner])).astype(cols.dtype)
+            return self._place(owner.to(cols.dtype), cols - begin).to(cols.dtype)
+        return self._place(owner, cols - self.bounds[:-1][owner]).astype(cols.dtype)
 
     def positions(self) -> np.ndarray:
         """Padded position of every node 0..n-1."""
@@ -118,12 +147,33 @@ class Layout:
         if self.world == 1:
             return g
         owner = np.searchsorted(self.bounds[1:-1], g, side="right")
-        return owner * self.stride + (g - self.bounds[:-1][owner])
+        return self._place(owner, g - self.bounds[:-1][owner])
+
+    def local_positions(self) -> np.ndarray:
+        """Padded positions of this rank's rows, in row order."""
+        return self._place(self.rank, np.arange(self.local_rows, dtype=np.int64))
 
     def tail_slice(self, rank=None):
+        """Where rank's two partial sums travel: the last TAIL floats of its last piece."""
         rank = self.rank if rank is None else rank
-        start = rank * self.stride + self.shard_len
+        start = (self.chunks - 1) * self.block + (rank + 1) * self.piece - TAIL
         return slice(start, start + TAIL)
+
+    def block_slice(self, c):
+        """Block c of the vector = the output of all-gather c."""
+        return slice(c * self.block, (c + 1) * self.block)
+
+    def piece_slice(self, c, rank=None):
+        """This rank's piece of block c = the input of all-gather c."""
+        rank = self.rank if rank is None else rank
+        start = c * self.block + rank * self.piece
+        return slice(start, start + self.piece)
+
+    def row_map(self):
+        """(base, piece, block) for spmv_c_pr_shard_create_chunked."""
+        if self.chunks == 1:
+            return self.row_offset, 0x7FFFFFFF, 0
+        return self.rank * self.piece, self.piece, self.block
 
 
 def shard_bounds(n: int, world: int, rank: int):
@@ -190,10 +240,11 @@ class HipEngine:
         # Creating the shard may build the matrix's tiled plan on the library's stream: whatever
         # filled the device arrays on torch's stream must be done first.
         torch.cuda.current_stream(self.device).synchronize()
-        self._shard = lib().spmv_c_pr_shard_create(self._A, self.layout.row_offset, self.layout.n,
-                                                   c_void_p(mask.data_ptr()))
+        base, piece, block = self.layout.row_map()
+        self._shard = lib().spmv_c_pr_shard_create_chunked(self._A, base, piece, block, self.layout.n,
+                                                           c_void_p(mask.data_ptr()))
         if not self._shard:
-            raise RuntimeError("spmv_c_pr_shard_create failed")
+            raise RuntimeError("spmv_c_pr_shard_create_chunked failed")
 
     def reset(self, dangling_sum: float) -> None:
         self._check(lib().spmv_c_pr_reset(self._shard, dangling_sum, self._stream()), "pr_reset")
@@ -213,6 +264,11 @@ class HipEngine:
         self._check(lib().spmv_c_pr_reduce(self._shard, c_void_p(target.data_ptr()), self._stream()), "pr_reduce")
         return target
 
+    def expand(self, r_old: torch.Tensor, cols_ready: int) -> None:
+        """Head start on the next step(r_old, ...): columns [0, cols_ready) of r_old are final."""
+        self._check(lib().spmv_c_pr_expand(self._shard, c_void_p(r_old.data_ptr()), cols_ready, self._stream()),
+                    "pr_expand")
+
     def step_and_commit(self, r_old: torch.Tensor, r_new: torch.Tensor, damping: float, tolerance: float) -> None:
         """Single-rank iteration: the step, then reduce + commit in one launch."""
         self._check(lib().spmv_c_pr_step(self._shard, c_void_p(r_old.data_ptr()), c_void_p(r_new.data_ptr()),
@@ -224,9 +280,11 @@ class HipEngine:
                     "pr_commit")
 
     def commit_gathered(self, gathered: torch.Tensor, tolerance: float) -> None:
+        """`gathered`: the whole vector; the ranks' partial sums sit in the tails of its last block."""
         lay = self.layout
-        self._check(lib().spmv_c_pr_commit_gathered(self._shard, c_void_p(gathered.data_ptr()), lay.world,
-                                                    lay.stride, lay.shard_len, tolerance, self._stream()),
+        last = gathered[lay.block_slice(lay.chunks - 1)]
+        self._check(lib().spmv_c_pr_commit_gathered(self._shard, c_void_p(last.data_ptr()), lay.world,
+                                                    lay.piece, lay.piece - TAIL, tolerance, self._stream()),
                     "pr_commit_gathered")
 
     def status(self):
@@ -278,6 +336,9 @@ class ShardedPageRank:
         self.mode = "gather"
         self._peer_ptrs = None
         self._peer_keepalive = []
+        # overlapped exchange: the collectives are issued from a side stream so that the compute stream is
+        # free to multiply block c while block c + 1 is still on the links
+        self._comm = torch.cuda.Stream(self.device) if self.device.type == "cuda" and layout.chunks > 1 else None
 
     def _device_vector(self, count):
         ptr = c_void_p(None)
@@ -317,9 +378,8 @@ class ShardedPageRank:
             lib().spmv_c_device_free(ptr)
         self._owned = []
 
-    def _my_slice(self, buf):
-        lay = self.layout
-        return buf[lay.row_offset: lay.row_offset + lay.stride]
+    def _my_slice(self, buf, c=0):
+        return buf[self.layout.piece_slice(c)]
 
     def _my_tail(self, buf):
         return buf[self.layout.tail_slice()].view(torch.float64)
@@ -430,8 +490,31 @@ class ShardedPageRank:
             dist.all_reduce(sums, group=self.group)        # 16 bytes: the sums and the cross-GPU barrier
             self.engine.commit(sums, tolerance)
             return
+        lay = self.layout
         self.engine.step(r_old, r_new, damping, self._my_tail(r_new))
-        dist.all_gather_into_tensor(r_new, self._my_slice(r_new), group=self.group)
+        if lay.chunks == 1:
+            dist.all_gather_into_tensor(r_new, self._my_slice(r_new), group=self.group)
+            self.engine.commit_gathered(r_new, tolerance)
+            return
+        # overlapped: one all-gather per block, issued back to back; as each completes, the next step's
+        # products for the columns of that block are computed (the engine skips them when the step comes)
+        works = []
+        if self._comm is not None:
+            stepped = torch.cuda.Event()
+            stepped.record()
+            self._comm.wait_event(stepped)
+            with torch.cuda.stream(self._comm):
+                for c in range(lay.chunks):
+                    works.append(dist.all_gather_into_tensor(r_new[lay.block_slice(c)], self._my_slice(r_new, c),
+                                                             group=self.group, async_op=True))
+        else:
+            for c in range(lay.chunks):
+                works.append(dist.all_gather_into_tensor(r_new[lay.block_slice(c)], self._my_slice(r_new, c),
+                                                         group=self.group, async_op=True))
+        for c, work in enumerate(works):
+            work.wait()                         # the compute stream waits for block c (no host block on a GPU)
+            if c + 1 < lay.chunks and hasattr(self.engine, "expand"):
+                self.engine.expand(r_new, (c + 1) * lay.block)
         self.engine.commit_gathered(r_new, tolerance)
 
     def run(self, damping=0.85, tolerance=1e-6, max_iterations=100, check_every=1):

@@ -253,11 +253,22 @@ typedef struct spmv_c_pr_status {                 /* device-side state, copied o
 
 spmv_c_pr_shard* spmv_c_pr_shard_create(const spmv_c_csr* A_local, int row_offset, int n_global,
                                         const uint8_t* d_dangling_mask);
+/* the same for a CHUNKED vector layout (the overlapped exchange of pagerank_dist.py): local row i sits at
+ * base + (i / piece) * block + i % piece — the vector is a sequence of blocks, block c holding piece c of every
+ * rank back to back (base = rank * piece, block = world * piece), so that one in-place all-gather per block
+ * delivers it while the blocks that have arrived are already being multiplied (spmv_c_pr_expand) */
+spmv_c_pr_shard* spmv_c_pr_shard_create_chunked(const spmv_c_csr* A_local, int base, int piece, int block,
+                                                int n_global, const uint8_t* d_dangling_mask);
 void spmv_c_pr_shard_destroy(spmv_c_pr_shard* shard);
 /* resets the iteration state; dangling_sum = dangling mass of the start vector */
 int spmv_c_pr_reset(spmv_c_pr_shard* shard, float dangling_sum, void* hip_stream);
 int spmv_c_pr_step(spmv_c_pr_shard* shard, const float* d_r_old, float* d_r_new, float damping,
                    void* hip_stream);
+/* optional head start on the NEXT spmv_c_pr_step (same d_r_old): columns [0, cols_ready) of d_r_old are final,
+ * the rest may still be arriving.  With the LDS-tiled engine the products of the entries in the strips inside
+ * that range are computed now (each strip once; the following step does only what is left); otherwise a no-op.
+ * spmv_c_pr_reset voids a head start. */
+int spmv_c_pr_expand(spmv_c_pr_shard* shard, const float* d_r_old, int64_t cols_ready, void* hip_stream);
 /* the same step, additionally storing every new value at the same offset of `num_peers` other
  * vectors (host array of device pointers: the peers' r_new buffers, IPC-mapped) — a push-style
  * all-gather over xGMI fused into the step's epilogue */

@@ -30,6 +30,15 @@ class OracleEngine:
         self.state = dict(dangling_sum=np.float32(0), residual=0.0, iterations=0, converged=False, done=False)
         self.mask = None
         self._sums = torch.zeros(2, dtype=torch.float64)
+        self.promised = []              # (cols_ready, copy of r_old[:cols_ready]) from expand(): must still hold at step()
+        self.head_starts = 0
+
+    def expand(self, r_old, cols_ready):
+        """The product's engine multiplies the columns [0, cols_ready) now; the double checks the promise that
+        they are final (step() compares them with what it finally sees)."""
+        assert 0 < cols_ready <= self.layout.padded and cols_ready % self.layout.block == 0
+        self.promised.append((cols_ready, r_old[:cols_ready].clone()))
+        self.head_starts += 1
 
     def column_sums(self):
         sums = np.zeros(self.layout.padded, np.float32)
@@ -44,6 +53,9 @@ class OracleEngine:
 
     def step(self, r_old, r_new, damping, sums_out=None):
         target = self._sums if sums_out is None else sums_out
+        for cols_ready, seen in self.promised:
+            assert torch.equal(r_old[:cols_ready], seen), "expand() was told about columns that changed afterwards"
+        self.promised = []
         if self.state["done"]:
             return target
         lay = self.layout
@@ -53,7 +65,7 @@ class OracleEngine:
         teleport = (np.float32(1.0) - d) / np.float32(lay.n)
         dterm = d * self.state["dangling_sum"] / np.float32(lay.n)
         fresh = (d * y + dterm + teleport).astype(np.float32)
-        sl = slice(lay.row_offset, lay.row_offset + lay.local_rows)
+        sl = lay.local_positions()
         diff = fresh - old[sl]
         r_new.numpy()[sl] = fresh
         target[0] = float(np.sum((diff * diff).astype(np.float32), dtype=np.float64))
@@ -112,7 +124,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, k, seed, dangling, tol, max_iter, check_every, out_dir, power_law=False):
+def _worker(rank, world, port, n, k, seed, dangling, tol, max_iter, check_every, out_dir, power_law=False, chunks=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -124,10 +136,10 @@ def _worker(rank, world, port, n, k, seed, dangling, tol, max_iter, check_every,
         oracle = importlib.import_module("oracle")
         if power_law:                       # unequal-nnz rows: boundaries by binary search on row_ptrs
             rp, ci, va = make_power_law_graph(spmv, n, seed)
-            lay = prd.Layout(n, world, rank, bounds=prd.Layout.equal_nnz_bounds(rp, world))
+            lay = prd.Layout(n, world, rank, bounds=prd.Layout.equal_nnz_bounds(rp, world), chunks=chunks)
         else:
             rp, ci, va = make_graph(spmv, n, k, seed, dangling)
-            lay = prd.Layout(n, world, rank)
+            lay = prd.Layout(n, world, rank, chunks=chunks)
         b, e = lay.row_begin, lay.row_end
         lrp = (rp[b:e + 1] - rp[b]).astype(np.int32)
         lci, lva = lay.remap_columns(ci[rp[b]:rp[e]]).astype(np.int32), va[rp[b]:rp[e]]
@@ -135,15 +147,17 @@ def _worker(rank, world, port, n, k, seed, dangling, tol, max_iter, check_every,
         pr = prd.ShardedPageRank(engine, lay).prepare()
         ranks, iters, res, conv = pr.run(0.85, tol, max_iter, check_every)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ranks=ranks, iters=iters, res=res, conv=conv,
-                 num_dangling=pr.num_dangling, local_rows=lay.local_rows, local_nnz=int(lrp[-1]))
+                 num_dangling=pr.num_dangling, local_rows=lay.local_rows, local_nnz=int(lrp[-1]),
+                 head_starts=engine.head_starts)
     finally:
         dist.destroy_process_group()
 
 
 def _run(world, tmp_path, n=600, k=6, seed=5, dangling=(3, 77, 401), tol=1e-6, max_iter=100, check_every=1,
-         power_law=False):
+         power_law=False, chunks=1):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, k, seed, dangling, tol, max_iter, check_every, str(tmp_path), power_law),
+    mp.spawn(_worker, args=(world, port, n, k, seed, dangling, tol, max_iter, check_every, str(tmp_path), power_law,
+                            chunks),
              nprocs=world, join=True)
     return [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
 
@@ -196,6 +210,22 @@ def test_equal_nnz_shards_on_a_power_law_graph(spmv, oracle, tmp_path, world):
     assert np.max(np.abs(outs[0]["ranks"].astype(np.float64) - want) / want) <= 1e-5
 
 
+@pytest.mark.parametrize("world,chunks,power_law", [(2, 3, False), (3, 2, False), (2, 4, True)])
+def test_overlapped_exchange_gives_the_same_bits(tmp_path, world, chunks, power_law):
+    """Layout(chunks=C): C in-place all-gathers (one per block of the chunk-major vector) with the next step's
+    head start after each.  The arithmetic per node does not change, so the ranks must equal the one-collective
+    form's bit for bit; the double also checks that every column range declared ready really was final."""
+    kw = dict(n=900, seed=11, power_law=True, max_iter=200) if power_law else dict(n=601)
+    (tmp_path / "plain").mkdir()
+    (tmp_path / "chunked").mkdir()
+    plain = _run(world, tmp_path / "plain", **kw)
+    chunked = _run(world, tmp_path / "chunked", chunks=chunks, **kw)
+    for a, b in zip(plain, chunked):
+        np.testing.assert_array_equal(a["ranks"], b["ranks"])
+        assert int(a["iters"]) == int(b["iters"]) and float(a["res"]) == float(b["res"])
+        assert int(a["head_starts"]) == 0 and int(b["head_starts"]) == (chunks - 1) * int(b["iters"])
+
+
 def test_running_ahead_of_the_convergence_check_changes_nothing(tmp_path):
     a = _run(2, tmp_path / "a", check_every=1) if (tmp_path / "a").mkdir() is None else None
     b = _run(2, tmp_path / "b", check_every=7) if (tmp_path / "b").mkdir() is None else None
@@ -245,6 +275,37 @@ def test_layout(spmv):
             t = lay.tail_slice(r)
             tails |= set(range(t.start, t.stop))
         assert not (tails & set(pos.tolist()))
+    # chunk-major layouts (overlapped exchange): positions unique and inside the vector, a rank's piece of block c
+    # holds exactly its rows [c * piece, (c + 1) * piece), tails in the last block and disjoint from every node
+    for n, world, chunks, align, bounds in [(10, 2, 2, None, None), (601, 3, 4, None, None), (601, 3, 4, 64, None),
+                                            (10, 3, 3, None, [0, 0, 3, 10]), (1_000_000, 8, 4, 4096, None),
+                                            (10, 1, 4, None, None)]:
+        lay = prd.Layout(n, world, 0, bounds=bounds, chunks=chunks, align=align)
+        pos = lay.positions()
+        assert len(set(pos.tolist())) == n and pos.max() < lay.padded == lay.chunks * lay.block
+        assert lay.block == lay.piece * world and lay.piece % 2 == 0
+        assert world == 1 or align is None or lay.piece % align == 0
+        np.testing.assert_array_equal(lay.remap_columns(np.arange(n, dtype=np.int32)), pos)
+        np.testing.assert_array_equal(lay.remap_columns(torch.arange(n, dtype=torch.int32)).numpy(), pos)
+        tails = set()
+        for r in range(world):
+            lr = prd.Layout(n, world, r, bounds=bounds, chunks=chunks, align=align)
+            mine = lr.local_positions()
+            np.testing.assert_array_equal(mine, pos[lr.row_begin:lr.row_end])
+            base, piece, block = lr.row_map()
+            i = np.arange(lr.local_rows)
+            want = base + i if piece == 0x7FFFFFFF else base + (i // piece) * block + i % piece
+            np.testing.assert_array_equal(mine, want)                                  # the engine's RowMap formula
+            for c in range(lr.chunks):
+                sl = lr.piece_slice(c)
+                inside = mine[(mine >= sl.start) & (mine < sl.stop)]
+                np.testing.assert_array_equal(inside, mine[c * lr.piece:(c + 1) * lr.piece])
+                assert lr.block_slice(c).start <= sl.start and sl.stop <= lr.block_slice(c).stop
+            if world > 1:
+                t = lr.tail_slice()
+                assert t.start % 2 == 0 and lr.block_slice(lr.chunks - 1).start <= t.start and t.stop == lr.piece_slice(lr.chunks - 1).stop
+                tails |= set(range(t.start, t.stop))
+        assert not (tails & set(pos.tolist())) and len(tails) == (4 * world if world > 1 else 0)
     rp = np.array([0, 10, 10, 11, 12, 40, 41], dtype=np.int32)
     np.testing.assert_array_equal(prd.Layout.equal_nnz_bounds(rp, 2), [0, 4, 6])
     assert prd.initial_dangling_mass(0, 10) == 0.0

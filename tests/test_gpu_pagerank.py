@@ -227,6 +227,117 @@ def test_two_shards_on_one_gpu_equal_one_shard(gpu, oracle):
         sp.engine.close()
 
 
+@pytest.mark.parametrize("chunks,align", [(3, None), (2, 32768)])
+def test_head_start_on_a_chunk_major_vector(gpu, oracle, chunks, align):
+    """The overlapped exchange's engine side (Layout(chunks=C) + spmv_c_pr_expand) on one device: two shards
+    large enough for the tiled engine; the host plays the per-block all-gathers and declares each block ready
+    as it "arrives".  Blocks that have not arrived hold NaN when the head start runs, and once everything has
+    been declared ready the foreign pieces are poisoned again before the step — so a head start that reads
+    ahead, or a step that multiplies a strip twice (or falls back to the direct kernel), shows up as NaN."""
+    torch = pytest.importorskip("torch")
+    prd = importlib.import_module("gpu-spmv_amd.pagerank_dist")
+    n = 400_000
+    rp, ci, va = graph(gpu, n, 8, 31, dangling=(5, 250_000))
+    dev = torch.device("cuda:0")
+
+    def sharded(lays):
+        out = []
+        for lay in lays:
+            b, e = lay.row_begin, lay.row_end
+            lrp = torch.from_numpy((rp[b:e + 1] - rp[b]).astype(np.int32)).to(dev)
+            lci = torch.from_numpy(lay.remap_columns(ci[rp[b]:rp[e]]).astype(np.int32)).to(dev)
+            out.append(prd.ShardedPageRank(prd.HipEngine(lrp, lci, torch.from_numpy(va[rp[b]:rp[e]]).to(dev), lay), lay))
+        sums = out[0].engine.column_sums() + out[1].engine.column_sums()
+        for sp in out:
+            mask = torch.zeros(sp.layout.padded, dtype=torch.uint8, device=dev)
+            mask[sp._pos] = (sums[sp._pos] == 0).to(torch.uint8)
+            sp.num_dangling = int(mask.sum().item())
+            sp.engine.set_dangling_mask(mask)
+            sp.reset()
+        return out
+
+    lays = [prd.Layout(n, 2, r, chunks=chunks, align=align) for r in range(2)]
+    assert lays[0].chunks == chunks and (align is None or lays[0].block % align == 0)
+    shards = sharded(lays)
+    for sp in shards:
+        assert gpu.csr_has_tiled_plan(sp.engine._A)          # else expand() is a no-op and the test says nothing
+    plain = sharded([prd.Layout(n, 2, r) for r in range(2)])
+    steps = 5
+    for k in range(steps):
+        olds = [sp.r[k & 1] for sp in shards]
+        news = [sp.r[(k + 1) & 1] for sp in shards]
+        for me, sp in enumerate(shards):
+            if k > 0:                                          # everything was declared ready: the step must not
+                for c in range(chunks):                        # look at the other rank's pieces again
+                    olds[me][lays[me].piece_slice(c, 1 - me)] = float("nan")
+            sp.engine.step(olds[me], news[me], 0.85, sp._my_tail(news[me]))
+            for c in range(chunks):                            # nothing of the new vector has arrived yet
+                news[me][lays[me].piece_slice(c, 1 - me)] = float("nan")
+        for c in range(chunks):
+            for src in (0, 1):                                 # all-gather of block c
+                sl = lays[src].piece_slice(c, src)
+                news[1 - src][sl] = news[src][sl]
+            for me, sp in enumerate(shards):
+                sp.engine.expand(news[me], (c + 1) * lays[me].block)
+        for sp in shards:
+            sp.engine.commit_gathered(sp.r[(k + 1) & 1], 0.0)
+        # the one-block form, same shards
+        for sp in plain:
+            sp.engine.step(sp.r[k & 1], sp.r[(k + 1) & 1], 0.85, sp._my_tail(sp.r[(k + 1) & 1]))
+        for src in (0, 1):
+            sl = plain[src].layout.piece_slice(0, src)
+            plain[1 - src].r[(k + 1) & 1][sl] = plain[src].r[(k + 1) & 1][sl]
+        for sp in plain:
+            sp.engine.commit_gathered(sp.r[(k + 1) & 1], 0.0)
+        got = [news[me][shards[me]._pos] for me in (0, 1)]
+        assert bool(torch.isfinite(got[0]).all())
+        torch.testing.assert_close(got[0], got[1], rtol=0, atol=0)
+        # (not bit for bit: the chunk-major numbering moves entries between strips, i.e. changes a row's summation order)
+        torch.testing.assert_close(got[0], plain[0].r[(k + 1) & 1][plain[0]._pos], rtol=2e-6, atol=0)
+    want, *_ = oracle.pagerank(rp, ci, va, num_cols=n, tolerance=0.0, max_iterations=steps, wide_sums=True)
+    v = shards[0].r[steps & 1][shards[0]._pos].double().cpu().numpy()
+    compare(v / v.sum(), want)
+    st = [sp.engine.status() for sp in shards + plain]
+    assert [x[0] for x in st] == [steps] * 4 and st[0][1] == st[1][1]
+    assert abs(st[0][1] - st[2][1]) <= 1e-12 + 1e-5 * st[2][1]
+    for sp in shards + plain:
+        sp.engine.close()
+
+
+def test_a_shard_keeps_its_plan_when_the_side_table_replaces_it(gpu, oracle):
+    """Two engines over the SAME row-pointer array but different column arrays (bench.py builds the plain and the
+    chunk-major numbering of one shard that way): the side table is keyed by the row pointers, so the second
+    engine's plan replaces the first's there, and closing either engine drops the entry.  A shard must go on
+    working on the plan it started with (shared ownership), not on freed memory."""
+    torch = pytest.importorskip("torch")
+    prd = importlib.import_module("gpu-spmv_amd.pagerank_dist")
+    n = 300_000
+    rp, ci, va = graph(gpu, n, 8, 77)
+    dev = torch.device("cuda:0")
+    lay = prd.Layout(n)
+    d_rp, d_va = torch.from_numpy(rp).to(dev), torch.from_numpy(va).to(dev)
+    d_ci = torch.from_numpy(ci).to(dev)
+    mirrored = (n - 1 - d_ci).contiguous()            # another numbering of the same graph's columns
+
+    def run(loop, steps=4):
+        loop.reset()
+        for k in range(steps):
+            loop.iterate(k, 0.85, 0.0)
+        torch.cuda.synchronize()
+        return loop.r[steps & 1].clone()
+
+    first = prd.ShardedPageRank(prd.HipEngine(d_rp, d_ci, d_va, lay), lay).prepare()
+    assert gpu.csr_has_tiled_plan(first.engine._A)
+    before = run(first)
+    second = prd.ShardedPageRank(prd.HipEngine(d_rp, mirrored, d_va, lay), lay).prepare()   # replaces the table's plan
+    torch.testing.assert_close(run(first), before, rtol=0, atol=0)
+    other = run(second)
+    second.engine.close()                               # drops the table entry both matrices share
+    torch.testing.assert_close(run(first), before, rtol=0, atol=0)
+    assert bool(torch.isfinite(other).all())
+    first.engine.close()
+
+
 def test_pagerank_through_the_tiled_engine(gpu, oracle):
     """A graph large enough (n >= 262144, >= 1 M entries) that pagerank() runs its steps through
     the LDS-tiled engine; same answer as the oracle."""

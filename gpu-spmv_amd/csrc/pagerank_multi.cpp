@@ -21,6 +21,9 @@
 // librccl is loaded lazily (dlopen) so that the library itself has no hard dependency on it; with
 // num_gpus == 1 the exchange degenerates to nothing and RCCL is not touched unless
 // SPMV_MULTI_GPU_FORCE_RCCL is set (the single-GPU test box exercises the collective path that way).
+// SPMV_MULTI_GPU_SHARE_DEVICES=1 lets more shards than devices run (shard p on device p % available) with the
+// slices exchanged by event-ordered device-to-device copies instead of RCCL — RCCL cannot put two ranks on one
+// device; this is how the P > 1 partition, layout and commit are tested on a one-GPU box.
 #include "internal.h"
 #include "pagerank_engine.h"
 #include "tiled.h"
@@ -84,6 +87,8 @@ struct DeviceShard {
     detail::PrShard shard;
     ncclComm_t comm = nullptr;
     bool have_header = false;
+    hipEvent_t stepped = nullptr;   // copy exchange: this shard's new slice is complete ...
+    hipEvent_t gathered = nullptr;  // ... and this shard has finished reading its peers' slices
 };
 
 void release(std::vector<DeviceShard>& shards, const Rccl* api) {
@@ -98,6 +103,8 @@ void release(std::vector<DeviceShard>& shards, const Rccl* api) {
             if (p) (void)hipFree(p);
         }
         if (d.stream) (void)hipStreamDestroy(d.stream);
+        if (d.stepped) (void)hipEventDestroy(d.stepped);
+        if (d.gathered) (void)hipEventDestroy(d.gathered);
     }
     shards.clear();
 }
@@ -130,17 +137,19 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
         return n <= 0 || num_gpus < 1 ? pagerank(adj, config) : result;
     }
     int available = 0;
-    if (hipGetDeviceCount(&available) != hipSuccess || available < num_gpus) {
+    const bool share_devices = std::getenv("SPMV_MULTI_GPU_SHARE_DEVICES") != nullptr;
+    if (hipGetDeviceCount(&available) != hipSuccess || available < 1 || (available < num_gpus && !share_devices)) {
         (void)hipGetLastError();
         return result;
     }
+    const bool by_copies = share_devices && available < num_gpus;     // several shards per device: no RCCL
     int previous_device = 0;
     (void)hipGetDevice(&previous_device);
 
     const int P = num_gpus;
     const bool force_rccl = std::getenv("SPMV_MULTI_GPU_FORCE_RCCL") != nullptr;
     const bool exchange = P > 1 || force_rccl;
-    const Rccl* api = exchange ? &rccl() : nullptr;
+    const Rccl* api = exchange && !by_copies ? &rccl() : nullptr;
     if (api && !api->ok) {
         std::fprintf(stderr, "spmv: librccl not available, pagerank_multi_gpu cannot exchange rank slices\n");
         return result;
@@ -191,7 +200,7 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
     std::vector<int> local_cols;
     for (int p = 0; p < P && ok; ++p) {
         DeviceShard& d = shards[p];
-        d.device = p;
+        d.device = p % available;
         const int rows = bounds[p + 1] - bounds[p];
         const int first = adj->row_ptrs[bounds[p]];
         const int local_nnz = adj->row_ptrs[bounds[p + 1]] - first;
@@ -202,8 +211,10 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
             const int c = adj->col_indices[first + j];
             local_cols[j] = c >= 0 && c < n ? position(c) : 0;   // node ids -> positions in the padded vector
         }
-        ok = hipSetDevice(p) == hipSuccess
+        ok = hipSetDevice(d.device) == hipSuccess
           && hipStreamCreate(&d.stream) == hipSuccess
+          && (!by_copies || (hipEventCreateWithFlags(&d.stepped, hipEventDisableTiming) == hipSuccess &&
+                             hipEventCreateWithFlags(&d.gathered, hipEventDisableTiming) == hipSuccess))
           && hipMalloc(reinterpret_cast<void**>(&d.d_row_ptrs), (static_cast<size_t>(rows) + 1) * sizeof(int)) == hipSuccess
           && hipMalloc(reinterpret_cast<void**>(&d.d_cols), static_cast<size_t>(std::max(local_nnz, 1)) * sizeof(int)) == hipSuccess
           && hipMalloc(reinterpret_cast<void**>(&d.d_vals), static_cast<size_t>(std::max(local_nnz, 1)) * sizeof(float)) == hipSuccess
@@ -239,7 +250,7 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
           && hipMalloc(reinterpret_cast<void**>(&sh.d_block_partials), 2 * sizeof(double) * static_cast<size_t>(pairs)) == hipSuccess
           && hipMemcpy(sh.d_state, &first_state, sizeof(first_state), hipMemcpyHostToDevice) == hipSuccess;
     }
-    if (ok && exchange) {
+    if (ok && exchange && !by_copies) {
         std::vector<int> devices(P);
         std::vector<ncclComm_t> comms(P, nullptr);
         for (int p = 0; p < P; ++p) devices[p] = p;
@@ -252,7 +263,7 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
     hipEvent_t seen[2] = {nullptr, nullptr};
     detail::PrState last_state{};
     if (ok) {
-        ok = hipSetDevice(0) == hipSuccess
+        ok = hipSetDevice(shards[0].device) == hipSuccess
           && hipHostMalloc(reinterpret_cast<void**>(&pinned), 2 * sizeof(detail::PrState)) == hipSuccess
           && hipEventCreateWithFlags(&seen[0], hipEventDisableTiming) == hipSuccess
           && hipEventCreateWithFlags(&seen[1], hipEventDisableTiming) == hipSuccess;
@@ -262,8 +273,16 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
             DeviceShard& d = shards[p];
             const float* r_old = d.r[iter & 1];
             float* r_new = d.r[(iter + 1) & 1];
-            ok = hipSetDevice(p) == hipSuccess
-              && detail::pr_step(d.shard, r_old, r_new, config->damping_factor, detail::PushTargets{}, d.stream) == hipSuccess;
+            ok = hipSetDevice(d.device) == hipSuccess;
+            if (ok && by_copies && iter > 0) {
+                // This step writes r_new = the vector the peers copied this shard's slice FROM during the exchange
+                // of step iter - 2.  Their `gathered` events (last recorded after the exchange of step iter - 1,
+                // later in the same streams) cover that.
+                for (int q = 0; q < P && ok; ++q) {
+                    if (q != p) ok = hipStreamWaitEvent(d.stream, shards[q].gathered, 0) == hipSuccess;
+                }
+            }
+            ok = ok && detail::pr_step(d.shard, r_old, r_new, config->damping_factor, detail::PushTargets{}, d.stream) == hipSuccess;
             if (!ok) break;
             if (exchange) {      // the two partial sums go into the tail of this device's own slice
                 double* tail = reinterpret_cast<double*>(r_new + p * stride + longest);
@@ -272,7 +291,25 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
                 ok = detail::pr_reduce_commit(d.shard, config->tolerance, d.stream) == hipSuccess;
             }
         }
-        if (ok && exchange) {
+        if (ok && by_copies) {
+            // every shard pulls every peer's slice (tail included) once that peer's step has finished
+            for (int p = 0; p < P && ok; ++p) {
+                ok = hipSetDevice(shards[p].device) == hipSuccess && hipEventRecord(shards[p].stepped, shards[p].stream) == hipSuccess;
+            }
+            for (int p = 0; p < P && ok; ++p) {
+                DeviceShard& d = shards[p];
+                ok = hipSetDevice(d.device) == hipSuccess;
+                for (int q = 0; q < P && ok; ++q) {
+                    if (q == p) continue;
+                    ok = hipStreamWaitEvent(d.stream, shards[q].stepped, 0) == hipSuccess
+                      && hipMemcpyAsync(d.r[(iter + 1) & 1] + q * stride, shards[q].r[(iter + 1) & 1] + q * stride,
+                                        static_cast<size_t>(stride) * sizeof(float), hipMemcpyDeviceToDevice, d.stream) == hipSuccess;
+                }
+                ok = ok && hipEventRecord(d.gathered, d.stream) == hipSuccess
+                  && detail::pr_commit_gathered(d.shard, d.r[(iter + 1) & 1], P, stride, longest, config->tolerance,
+                                                d.stream) == hipSuccess;
+            }
+        } else if (ok && exchange) {
             ok = api->GroupStart() == ncclSuccess;
             for (int p = 0; p < P && ok; ++p) {
                 float* r_new = shards[p].r[(iter + 1) & 1];
@@ -281,13 +318,13 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
             }
             ok = api->GroupEnd() == ncclSuccess && ok;
             for (int p = 0; p < P && ok; ++p) {
-                ok = hipSetDevice(p) == hipSuccess
+                ok = hipSetDevice(shards[p].device) == hipSuccess
                   && detail::pr_commit_gathered(shards[p].shard, shards[p].r[(iter + 1) & 1], P, stride, longest,
                                                 config->tolerance, shards[p].stream) == hipSuccess;
             }
         }
         if (!ok) break;
-        ok = hipSetDevice(0) == hipSuccess
+        ok = hipSetDevice(shards[0].device) == hipSuccess
           && hipMemcpyAsync(&pinned[iter & 1], shards[0].shard.d_state, sizeof(detail::PrState), hipMemcpyDeviceToHost,
                             shards[0].stream) == hipSuccess
           && hipEventRecord(seen[iter & 1], shards[0].stream) == hipSuccess;
@@ -297,10 +334,10 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
         }
     }
     for (int p = 0; p < P && ok; ++p) {
-        ok = hipSetDevice(p) == hipSuccess && hipStreamSynchronize(shards[p].stream) == hipSuccess;
+        ok = hipSetDevice(shards[p].device) == hipSuccess && hipStreamSynchronize(shards[p].stream) == hipSuccess;
     }
     if (ok) {
-        ok = hipSetDevice(0) == hipSuccess
+        ok = hipSetDevice(shards[0].device) == hipSuccess
           && hipMemcpy(&last_state, shards[0].shard.d_state, sizeof(last_state), hipMemcpyDeviceToHost) == hipSuccess;
     }
 

@@ -5,7 +5,9 @@
 //   multi_gpu_pagerank bounds         CPU only: the equal-nnz row boundaries
 //   multi_gpu_pagerank run [N]        needs N (default 1) GPUs: pagerank_multi_gpu(N) == pagerank() on a uniform
 //                                     and on a power-law graph, plain and through SPMV_NUM_GPUS; with N == 1 the
-//                                     collective path is exercised too (SPMV_MULTI_GPU_FORCE_RCCL)
+//                                     collective path is exercised too (SPMV_MULTI_GPU_FORCE_RCCL), and the P > 1
+//                                     partition / layout / commit with 2, 3 and 8 shards sharing the device
+//                                     (SPMV_MULTI_GPU_SHARE_DEVICES: slices exchanged by device copies)
 // Plain host C++: g++ -Iinclude ... -lspmv_amd.
 #include "spmv/pagerank.h"
 #include "spmv/spmv.h"
@@ -117,6 +119,22 @@ static void test_run(int gpus) {
             EXPECT(routed.ranks && multi.ranks && routed.iterations == multi.iterations);
             if (routed.ranks && multi.ranks) EXPECT(worst_relative(routed, multi, n) <= 2e-6);
             pagerank_free(&routed);
+        }
+        if (gpus == 1) {                                    // P > 1 shards on the one device, exchange by copies
+            setenv("SPMV_MULTI_GPU_SHARE_DEVICES", "1", 1);
+            for (int shards : {2, 3, 8}) {
+                PageRankResult shared = pagerank_multi_gpu(g, &cfg, shards);
+                EXPECT(shared.ranks != nullptr);
+                if (shared.ranks) {
+                    EXPECT(shared.converged == single.converged && std::abs(shared.iterations - single.iterations) <= 1);
+                    if (shared.iterations == single.iterations) EXPECT(worst_relative(shared, single, n) <= 2e-6);
+                    double sum = 0.0;
+                    for (int i = 0; i < n; ++i) sum += shared.ranks[i];
+                    EXPECT(std::fabs(sum - 1.0) < 1e-4);
+                }
+                pagerank_free(&shared);
+            }
+            unsetenv("SPMV_MULTI_GPU_SHARE_DEVICES");
         }
         // more devices than the machine has: an empty result, not a crash
         PageRankResult none = pagerank_multi_gpu(g, &cfg, 1024);

@@ -1194,6 +1194,17 @@ void choose_shape(long long num_rows, long long num_cols, long long nnz, int* st
             r = stretched <= kMaxTileRows ? stretched : snapped(rounds + 1);
         }
     }
+    // The strip width was chosen for the tile count before the snap; the snap usually halves the tiles (doubles
+    // the runs), so a narrower strip may do now — half the LDS per phase-1 workgroup, twice the wavefronts per CU.
+    // Narrow only while the runs stay comfortably long: C4 (1 M power-law rows) 16384 -> 8192 columns, runs
+    // 361 -> 182: 44.0 -> 41.9 us; C5 at 8192 would have 128-slot runs: 503 -> 547 us (profiles/r02_shape_sweep.txt,
+    // r02_c4_sweep.txt), hence the margin over kTargetRun.
+    {
+        constexpr long long kComfortableRun = 160;
+        int narrower = 4096;
+        while (narrower < w && nnz / (strips_for(narrower) * tiles_for(r)) < kComfortableRun) narrower <<= 1;
+        w = narrower;
+    }
     if (const char* env = std::getenv("SPMV_TILED_STRIP")) {
         const int v = std::atoi(env);
         if (v == 4096 || v == 8192 || v == 16384 || v == 32768) w = v;

@@ -224,12 +224,32 @@ int csr_deserialize(CSRMatrix* mat, const char* filename) {
     if (!get(f.get(), header, 3) || header[0] < 0 || header[1] < 0 || header[2] < 0) {
         return detail::code(SpMVError::FILE_IO);
     }
+    // The header is not trusted: the payload it promises must be in the file before anything is allocated
+    // (a corrupt nnz field must not turn into a multi-gigabyte allocation), ...
+    const unsigned long long promised = 8ULL * static_cast<unsigned long long>(header[2]) +
+                                        4ULL * (static_cast<unsigned long long>(header[0]) + 1);
+    const long here = ftell(f.get());
+    if (here < 0 || fseek(f.get(), 0, SEEK_END) != 0) return detail::code(SpMVError::FILE_IO);
+    const long end = ftell(f.get());
+    if (end < here || static_cast<unsigned long long>(end - here) < promised || fseek(f.get(), here, SEEK_SET) != 0) {
+        return detail::code(SpMVError::FILE_IO);
+    }
     adopt_shape(mat, header[0], header[1], header[2]);
 
     const size_t nnz = static_cast<size_t>(mat->nnz);
-    const bool ok = get(f.get(), mat->values, nnz)
-                 && get(f.get(), mat->col_indices, nnz)
-                 && get(f.get(), mat->row_ptrs, static_cast<size_t>(mat->num_rows) + 1);
+    bool ok = get(f.get(), mat->values, nnz)
+           && get(f.get(), mat->col_indices, nnz)
+           && get(f.get(), mat->row_ptrs, static_cast<size_t>(mat->num_rows) + 1);
+    // ... and the arrays must describe a CSR matrix: every later loop (CPU and GPU) indexes with them unchecked
+    if (ok) {
+        ok = mat->row_ptrs[0] == 0 && mat->row_ptrs[mat->num_rows] == mat->nnz;
+        for (int r = 0; ok && r < mat->num_rows; ++r) ok = mat->row_ptrs[r] <= mat->row_ptrs[r + 1];
+        for (size_t j = 0; ok && j < nnz; ++j) ok = mat->col_indices[j] >= 0 && mat->col_indices[j] < mat->num_cols;
+    }
+    if (!ok) {                                   // never leave half-read arrays behind a plausible header
+        adopt_shape(mat, 0, 0, 0);
+        mat->row_ptrs[0] = 0;
+    }
     return detail::code(ok ? SpMVError::SUCCESS : SpMVError::FILE_IO);
 }
 

@@ -264,6 +264,15 @@ int ell_deserialize(ELLMatrix* mat, const char* filename) {
         header[0] < 0 || header[1] < 0 || header[2] < 0) {
         return detail::code(SpMVError::FILE_IO);
     }
+    // the header is not trusted: the slabs it promises must be in the file before anything is allocated
+    const unsigned long long promised = 8ULL * static_cast<unsigned long long>(header[0]) * static_cast<unsigned long long>(header[2]);
+    const long here = ftell(f.get());
+    if (here < 0 || fseek(f.get(), 0, SEEK_END) != 0) return detail::code(SpMVError::FILE_IO);
+    const long end = ftell(f.get());
+    if (end < here || static_cast<unsigned long long>(end - here) < promised || promised > 0x7fffffffULL * 8ULL ||
+        fseek(f.get(), here, SEEK_SET) != 0) {
+        return detail::code(SpMVError::FILE_IO);
+    }
     adopt_shape(mat, header[0], header[1], header[2]);
 
     const size_t n = slots(mat);
@@ -272,6 +281,9 @@ int ell_deserialize(ELLMatrix* mat, const char* filename) {
         ok = fread(mat->values, sizeof(float), n, f.get()) == n
           && fread(mat->col_indices, sizeof(int), n, f.get()) == n;
     }
+    // column indices are used unchecked by every kernel: -1 marks padding, anything else must be a column
+    for (size_t j = 0; ok && j < n; ++j) ok = mat->col_indices[j] >= -1 && mat->col_indices[j] < mat->num_cols;
+    if (!ok) adopt_shape(mat, 0, 0, 0);
     return detail::code(ok ? SpMVError::SUCCESS : SpMVError::FILE_IO);
 }
 

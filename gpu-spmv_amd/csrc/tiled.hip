@@ -18,33 +18,35 @@
 //        matrix = 16 .. 128 KiB) into LDS, streams its share of the strip's slots (value, local column) with
 //        16-byte loads, gathers x from LDS and stores the products — same order, so
 //        loads and stores are all contiguous.
-//   phase 2 "reduce" : a workgroup owns one row tile (R rows in dynamic LDS, R a multiple of 64
-//        up to 9984 = 39 KiB, stretched so that the tiles fill whole rounds of resident workgroups).
-//        The tile's slots are one contiguous run per strip (cell table); a wavefront takes a run,
-//        loads 4 products (16 B) + 4 row deltas (4 B) per lane, rebuilds the rows with an in-lane prefix
-//        and one DPP wavefront scan, adds each product into the LDS tile and finally the tile is written
-//        out with coalesced stores (optionally through the fused PageRank update).
-//        gfx950's ds_add_f32 is ~30x slower than its integer LDS atomics (0.38 vs 11.7
-//        lanes/clk/CU measured), so the add is a compare-and-swap on the word's integer
-//        image (3.5 lanes/clk/CU measured; race-free for any row multiplicity).
+//   phase 2 "reduce" : a workgroup (1024 threads) owns one row tile: R rows of DOUBLES in dynamic LDS, R a
+//        multiple of 64 up to 9984 = 78 KiB, two tiles per CU, R stretched so that the tiles fill whole rounds
+//        of the 512 resident workgroups.  The tile's slots are one contiguous run per strip (cell table); a
+//        wavefront takes a run, loads 4 products (16 B) + 4 row deltas (4 B) per lane, rebuilds the rows with an
+//        in-lane prefix and one DPP wavefront scan, adds each product into the tile with the hardware
+//        ds_add_f64 and finally the tile is rounded to fp32 and written out with coalesced stores (optionally
+//        through the fused PageRank update).  Why doubles: gfx950's ds_add_f32 runs at 0.38 lanes/clk/CU, a
+//        compare-and-swap add at 3.4 but with retry storms when the tile's wavefronts meet on hot rows (round
+//        1: phase 2 VALU-bound at ~225 us whatever was changed), ds_add_f64 at 3.5 (8.6 on consecutive rows)
+//        with no retries (tools/lds_bench.hip, profiles/r02_lds_bench.txt, r02_phase2_counters.txt).
 //   folding : when every stored entry of a column has the same bits, the value stream is dropped
 //        and phase 1 gathers w_j * x_j from LDS (strip_weight_kernel, FOLD instantiation).
 //   both phases walk their work lists in per-XCD contiguous slices (xcd_contiguous).
-//   long rows (more than min(4096, 8 entries per strip)) would make many lanes fight over one
-//        LDS word; they are left out of the cells and summed in 512-entry chunks by extra
-//        wavefronts of the phase-1 grid (direct gather); their chunk sums seed the tiles in phase 2.
-//   build : two passes of one kernel over batches of <= ~5.5 K entries (rows of ONE tile): the batch is
-//        binned by strip in LDS, ranked inside every bin by (row, column), and — second pass — written
-//        to its cells at offsets fixed by a scan over (strip, tile, batch) counts.  No global atomics,
-//        so the layout is a pure function of the matrix (reproducible), and a cell's slots leave the
-//        workgroup as contiguous segments.
+//   long rows (more than min(4096, 8 entries per strip)) would make many lanes meet on one LDS word; they are
+//        left out of the cells and summed in 512-entry chunks by extra wavefronts of the phase-1 grid (direct
+//        gather) into one slot per chunk; phase 2's tile start folds a long row's chunk sums in chunk order.
+//   build : batches of <= ~5 K entries (consecutive rows of ONE tile).  Ranking pass: the batch is binned by
+//        strip in LDS and every entry ranked inside its bin by (row, column, source index); it leaves a 4-byte
+//        record per entry (position inside its group, row delta, skip markers) and the group sizes.  One thread
+//        per cell then places the groups of its batches, a scan over (strip, tile) gives the cell offsets, and
+//        the placing pass writes every entry straight to its slot.  No global atomics anywhere, so the layout
+//        is a pure function of the matrix.
 //
-// HBM traffic per entry: 6 B read + 4 B written in phase 1, 5 B read in phase 2
-// (15 B vs CSR's 8 B) — but all of it is streamed, which beats one 64-byte random
-// fetch per entry by a wide margin once x leaves L2.
-// The order in which a row's products are added depends on scheduling, so the low
-// bits of y may differ from run to run (as with any atomic accumulation; the
-// reference's merge-path kernel has the same property).
+// HBM traffic per slot: 6 B read + 4 B written in phase 1, 5 B read in phase 2 (15 B vs CSR's 8 B per entry) —
+// but all of it is streamed, which beats one 64-byte random fetch per entry by a wide margin once x leaves L2.
+// Reproducibility: layout and long-row sums are order-free; inside a tile the products of a row meet in
+// scheduling order, but they are added as doubles (every fp32 product is exact there, the sum of a row's
+// products carries ~29 spare bits) and rounded to fp32 once, so two runs give the same bits
+// (tests/test_gpu_spmv.py holds this on C4 and C5 shapes).
 #include "tiled.h"
 #include "device_common.h"
 #include "pagerank_engine.h"

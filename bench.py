@@ -168,51 +168,59 @@ def main():
     # products of block c computed while block c + 1 is on the links; pagerank_dist.py).  Same collectives, same
     # kernels, another numbering of the vector — so it is first checked against the one-collective run (4 steps
     # from the start vector, every node within 1e-5 relative on every rank), and the recorded number is whichever
-    # form was faster over the same W + K steps; config.exchange says which.  SPMV_PR_OVERLAP=0 skips it,
-    # SPMV_PR_OVERLAP=<C> sets the number of blocks (default 4).
-    overlap_blocks = int(os.environ.get("SPMV_PR_OVERLAP", "4"))
-    if world > 1 and overlap_blocks > 1:
-        lay2 = prd.Layout(n, world, rank, chunks=overlap_blocks)
-        cols2 = torch.empty_like(cols)
-        scratch_ptrs, scratch_vals = torch.empty_like(row_ptrs), torch.empty_like(vals)
-        status = spmv.lib().spmv_c_gen_uniform_rows(args.seed, row_begin, local_rows, n, k, scratch_ptrs.data_ptr(),
-                                                    cols2.data_ptr(), scratch_vals.data_ptr(), stream)   # the node ids again
-        assert status == 0, spmv.spmv_error_string(status)
-        torch.cuda.synchronize()
-        del scratch_ptrs, scratch_vals
-        cols2_v = cols2[: local_rows * k]
-        cols2_v.copy_(lay2.remap_columns(cols2_v))
-        # (its own copy of the row pointers: the library keys a matrix's cached plan by that array)
-        row_ptrs2 = row_ptrs.clone()
-        engine2 = prd.HipEngine(row_ptrs2, cols2_v, vals_v, lay2)
-        pr2 = prd.ShardedPageRank(engine2, lay2).prepare()
-
+    # form was fastest over the same W + K steps; config.exchange says which.  SPMV_PR_OVERLAP=0 skips it,
+    # SPMV_PR_OVERLAP=<C>[,<C>...] sets the block counts to try (default 4,2).
+    candidates = [int(c) for c in os.environ.get("SPMV_PR_OVERLAP", "4,2").split(",") if c.strip()]
+    candidates = [c for c in candidates if c > 1]
+    if world > 1 and candidates:
         def after(loop, steps):
             loop.reset()
             for i in range(steps):
                 loop.iterate(i, damping, never)
             torch.cuda.synchronize()
             return loop.r[steps & 1][loop._pos].clone()
-        ref, got = after(pr, 4), after(pr2, 4)
-        worst = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max())
-        agree = torch.tensor([1 if worst <= 1e-5 else 0], dtype=torch.int32, device=device)
-        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-        del ref, got
-        exchange_trials = {"gather_ms_per_step": round(elapsed / args.steps * 1e3, 4), "overlapped_blocks": overlap_blocks,
-                           "overlapped_max_rel_diff_after_4_steps": worst, "overlapped_agrees": bool(int(agree.item()))}
-        if int(agree.item()) == 1:
-            elapsed2 = timed(pr2, engine2)
-            exchange_trials["overlapped_ms_per_step"] = round(elapsed2 / args.steps * 1e3, 4)
-            if elapsed2 < elapsed:          # the same on every rank (both are all-reduced maxima)
-                engine.close()
-                pr.close()
-                engine, pr, layout, elapsed = engine2, pr2, lay2, elapsed2
-                cols_v = cols2_v
-                exchange = "gather-overlapped x%d" % overlap_blocks
-                engine2 = pr2 = None
-        if engine2 is not None:
-            engine2.close()
-            pr2.close()
+        ref = after(pr, 4)
+        exchange_trials = {"gather_ms_per_step": round(elapsed / args.steps * 1e3, 4), "overlapped": []}
+        best = (elapsed, engine, pr, layout, cols_v, exchange)
+        for blocks in candidates:
+            lay2 = prd.Layout(n, world, rank, chunks=blocks)
+            cols2 = torch.empty_like(cols)
+            scratch_ptrs, scratch_vals = torch.empty_like(row_ptrs), torch.empty_like(vals)
+            status = spmv.lib().spmv_c_gen_uniform_rows(args.seed, row_begin, local_rows, n, k, scratch_ptrs.data_ptr(),
+                                                        cols2.data_ptr(), scratch_vals.data_ptr(), stream)   # the node ids again
+            assert status == 0, spmv.spmv_error_string(status)
+            torch.cuda.synchronize()
+            del scratch_ptrs, scratch_vals
+            cols2_v = cols2[: local_rows * k]
+            cols2_v.copy_(lay2.remap_columns(cols2_v))
+            # (its own copy of the row pointers: the library keys a matrix's cached plan by that array)
+            engine2 = prd.HipEngine(row_ptrs.clone(), cols2_v, vals_v, lay2)
+            pr2 = prd.ShardedPageRank(engine2, lay2).prepare()
+            got = after(pr2, 4)
+            worst = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max())
+            agree = torch.tensor([1 if worst <= 1e-5 else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            del got
+            trial = {"blocks": blocks, "max_rel_diff_after_4_steps": worst, "agrees": bool(int(agree.item()))}
+            keep = False
+            if trial["agrees"]:
+                elapsed2 = timed(pr2, engine2)
+                trial["ms_per_step"] = round(elapsed2 / args.steps * 1e3, 4)
+                keep = elapsed2 < best[0]           # the same verdict on every rank (all-reduced maxima)
+            exchange_trials["overlapped"].append(trial)
+            if keep:
+                if best[1] is not engine:           # the plain loop stays until the end (it made `ref`)
+                    best[1].close()
+                    best[2].close()
+                best = (elapsed2, engine2, pr2, lay2, cols2_v, "gather-overlapped x%d" % blocks)
+            else:
+                engine2.close()
+                pr2.close()
+        del ref
+        if best[1] is not engine:
+            engine.close()
+            pr.close()
+        elapsed, engine, pr, layout, cols_v, exchange = best
 
     bytes_per_step = csr_bytes(n, n, nnz_total)
     ms_per_step = elapsed / args.steps * 1e3

@@ -15,8 +15,10 @@
 //     over xGMI (RCCL, single-process ncclCommInitAll, one stream per device, grouped calls), then
 //     pr_commit_gathered folds the P partial pairs in device order — identical state on every device, no
 //     separate all-reduce;
-//   * the host runs one step ahead of the convergence check (device-side `done` flag, pinned mirror), as the
-//     single-GPU loop does; RCCL failures surface as an empty result, never as a hang on our side.
+//   * one host thread per device drives its stream (issuing for eight devices from one thread would take about as
+//     long as the step itself); each runs one step ahead of the convergence check (device-side `done` flag,
+//     pinned mirror), as the single-GPU loop does; a failure on any device releases the others
+//     (ncclCommAbort) and surfaces as an empty result, not as a hang.
 //
 // librccl is loaded lazily (dlopen) so that the library itself has no hard dependency on it; with
 // num_gpus == 1 the exchange degenerates to nothing and RCCL is not touched unless
@@ -35,10 +37,13 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace spmv {
@@ -50,6 +55,7 @@ constexpr int kTail = 4;        // floats appended to every slice: two doubles o
 struct Rccl {
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;       // optional
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -66,6 +72,7 @@ const Rccl& rccl() {
         if (!lib) return;
         api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(lib, "ncclCommAbort"));
         api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(lib, "ncclAllGather"));
         api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(lib, "ncclGroupStart"));
         api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
@@ -73,6 +80,42 @@ const Rccl& rccl() {
     });
     return api;
 }
+
+// host rendezvous of the per-shard threads (copy exchange only); a failing thread releases everybody
+class Rendezvous {
+public:
+    explicit Rendezvous(int parties) : parties_(parties) {}
+    // returns false when any party has failed (then or earlier)
+    bool arrive(bool fine) {
+        std::unique_lock<std::mutex> lock(m_);
+        if (!fine) failed_ = true;
+        if (failed_) {
+            cv_.notify_all();
+            return false;
+        }
+        const long generation = generation_;
+        if (++waiting_ == parties_) {
+            waiting_ = 0;
+            ++generation_;
+            cv_.notify_all();
+        } else {
+            cv_.wait(lock, [&] { return generation_ != generation || failed_; });
+        }
+        return !failed_;
+    }
+    void fail() {
+        std::lock_guard<std::mutex> lock(m_);
+        failed_ = true;
+        cv_.notify_all();
+    }
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    const int parties_;
+    int waiting_ = 0;
+    long generation_ = 0;
+    bool failed_ = false;
+};
 
 // what one device holds
 struct DeviceShard {
@@ -86,6 +129,7 @@ struct DeviceShard {
     CSRMatrix header;               // wraps the three arrays (side-table key for the tiled plan)
     detail::PrShard shard;
     ncclComm_t comm = nullptr;
+    bool comm_aborted = false;      // ncclCommAbort already released it
     bool have_header = false;
     hipEvent_t stepped = nullptr;   // copy exchange: this shard's new slice is complete ...
     hipEvent_t gathered = nullptr;  // ... and this shard has finished reading its peers' slices
@@ -95,7 +139,7 @@ void release(std::vector<DeviceShard>& shards, const Rccl* api) {
     for (DeviceShard& d : shards) {
         if (hipSetDevice(d.device) != hipSuccess) continue;
         if (d.stream) (void)hipStreamSynchronize(d.stream);
-        if (d.comm && api) (void)api->CommDestroy(d.comm);
+        if (d.comm && api && !d.comm_aborted) (void)api->CommDestroy(d.comm);
         if (d.have_header) detail::aux_drop(d.header.d_row_ptrs);          // the shard's tiled plan, if any
         for (void* p : {static_cast<void*>(d.d_row_ptrs), static_cast<void*>(d.d_cols), static_cast<void*>(d.d_vals),
                         static_cast<void*>(d.d_mask), static_cast<void*>(d.r[0]), static_cast<void*>(d.r[1]),
@@ -258,83 +302,95 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
         for (int p = 0; p < P; ++p) shards[p].comm = comms[p];
     }
 
-    // ---- the loop: the host enqueues step k + 1 on every device before it looks at the outcome of step k
-    detail::PrState* pinned = nullptr;
-    hipEvent_t seen[2] = {nullptr, nullptr};
+    // ---- the loop: ONE HOST THREAD PER SHARD (a step is a handful of launches per device; issued from one thread
+    // for eight devices they take about as long as the step itself).  Every thread enqueues step k + 1 before it
+    // looks at the outcome of step k (pinned mirror of its own device's state; the states are identical on all
+    // devices, so all threads leave the loop after the same step).  With RCCL nothing but the collective couples
+    // the threads; the copy exchange needs two host rendezvous per step (an event must have been recorded before
+    // another thread can wait on it).
     detail::PrState last_state{};
-    if (ok) {
-        ok = hipSetDevice(shards[0].device) == hipSuccess
-          && hipHostMalloc(reinterpret_cast<void**>(&pinned), 2 * sizeof(detail::PrState)) == hipSuccess
-          && hipEventCreateWithFlags(&seen[0], hipEventDisableTiming) == hipSuccess
-          && hipEventCreateWithFlags(&seen[1], hipEventDisableTiming) == hipSuccess;
+    Rendezvous meet(P);
+    std::vector<detail::PrState*> pinned(P, nullptr);
+    std::vector<std::array<hipEvent_t, 2>> seen(P, std::array<hipEvent_t, 2>{nullptr, nullptr});
+    for (int p = 0; p < P && ok; ++p) {
+        ok = hipSetDevice(shards[p].device) == hipSuccess
+          && hipHostMalloc(reinterpret_cast<void**>(&pinned[p]), 2 * sizeof(detail::PrState)) == hipSuccess
+          && hipEventCreateWithFlags(&seen[p][0], hipEventDisableTiming) == hipSuccess
+          && hipEventCreateWithFlags(&seen[p][1], hipEventDisableTiming) == hipSuccess;
     }
-    for (int iter = 0; ok && iter < config->max_iterations; ++iter) {
-        for (int p = 0; p < P && ok; ++p) {
-            DeviceShard& d = shards[p];
+    auto drive = [&](int p) {
+        DeviceShard& d = shards[p];
+        bool fine = hipSetDevice(d.device) == hipSuccess;
+        for (int iter = 0; fine && iter < config->max_iterations; ++iter) {
             const float* r_old = d.r[iter & 1];
             float* r_new = d.r[(iter + 1) & 1];
-            ok = hipSetDevice(d.device) == hipSuccess;
-            if (ok && by_copies && iter > 0) {
+            if (by_copies && iter > 0) {
                 // This step writes r_new = the vector the peers copied this shard's slice FROM during the exchange
                 // of step iter - 2.  Their `gathered` events (last recorded after the exchange of step iter - 1,
-                // later in the same streams) cover that.
-                for (int q = 0; q < P && ok; ++q) {
-                    if (q != p) ok = hipStreamWaitEvent(d.stream, shards[q].gathered, 0) == hipSuccess;
+                // later in the same streams; the rendezvous that ended that step made sure they are recorded).
+                for (int q = 0; q < P && fine; ++q) {
+                    if (q != p) fine = hipStreamWaitEvent(d.stream, shards[q].gathered, 0) == hipSuccess;
                 }
             }
-            ok = ok && detail::pr_step(d.shard, r_old, r_new, config->damping_factor, detail::PushTargets{}, d.stream) == hipSuccess;
-            if (!ok) break;
-            if (exchange) {      // the two partial sums go into the tail of this device's own slice
+            fine = fine && detail::pr_step(d.shard, r_old, r_new, config->damping_factor, detail::PushTargets{}, d.stream) == hipSuccess;
+            if (fine && exchange) {      // the two partial sums go into the tail of this device's own slice
                 double* tail = reinterpret_cast<double*>(r_new + p * stride + longest);
-                ok = detail::pr_reduce(d.shard, tail, d.stream) == hipSuccess;
-            } else {
-                ok = detail::pr_reduce_commit(d.shard, config->tolerance, d.stream) == hipSuccess;
+                fine = detail::pr_reduce(d.shard, tail, d.stream) == hipSuccess;
+            } else if (fine) {
+                fine = detail::pr_reduce_commit(d.shard, config->tolerance, d.stream) == hipSuccess;
             }
-        }
-        if (ok && by_copies) {
-            // every shard pulls every peer's slice (tail included) once that peer's step has finished
-            for (int p = 0; p < P && ok; ++p) {
-                ok = hipSetDevice(shards[p].device) == hipSuccess && hipEventRecord(shards[p].stepped, shards[p].stream) == hipSuccess;
-            }
-            for (int p = 0; p < P && ok; ++p) {
-                DeviceShard& d = shards[p];
-                ok = hipSetDevice(d.device) == hipSuccess;
-                for (int q = 0; q < P && ok; ++q) {
+            if (fine && by_copies) {
+                // every shard pulls every peer's slice (tail included) once that peer's step has finished
+                fine = hipEventRecord(d.stepped, d.stream) == hipSuccess;
+                if (!meet.arrive(fine)) { fine = false; break; }
+                for (int q = 0; q < P && fine; ++q) {
                     if (q == p) continue;
-                    ok = hipStreamWaitEvent(d.stream, shards[q].stepped, 0) == hipSuccess
-                      && hipMemcpyAsync(d.r[(iter + 1) & 1] + q * stride, shards[q].r[(iter + 1) & 1] + q * stride,
-                                        static_cast<size_t>(stride) * sizeof(float), hipMemcpyDeviceToDevice, d.stream) == hipSuccess;
+                    fine = hipStreamWaitEvent(d.stream, shards[q].stepped, 0) == hipSuccess
+                        && hipMemcpyAsync(r_new + q * stride, shards[q].r[(iter + 1) & 1] + q * stride,
+                                          static_cast<size_t>(stride) * sizeof(float), hipMemcpyDeviceToDevice, d.stream) == hipSuccess;
                 }
-                ok = ok && hipEventRecord(d.gathered, d.stream) == hipSuccess
-                  && detail::pr_commit_gathered(d.shard, d.r[(iter + 1) & 1], P, stride, longest, config->tolerance,
-                                                d.stream) == hipSuccess;
+                fine = fine && hipEventRecord(d.gathered, d.stream) == hipSuccess;
+                if (!meet.arrive(fine)) { fine = false; break; }
+            } else if (fine && exchange) {
+                fine = api->AllGather(r_new + p * stride, r_new, static_cast<size_t>(stride), ncclFloat, d.comm, d.stream) == ncclSuccess;
             }
-        } else if (ok && exchange) {
-            ok = api->GroupStart() == ncclSuccess;
-            for (int p = 0; p < P && ok; ++p) {
-                float* r_new = shards[p].r[(iter + 1) & 1];
-                ok = api->AllGather(r_new + p * stride, r_new, static_cast<size_t>(stride), ncclFloat, shards[p].comm,
-                                    shards[p].stream) == ncclSuccess;
+            if (fine && exchange) {
+                fine = detail::pr_commit_gathered(d.shard, r_new, P, stride, longest, config->tolerance, d.stream) == hipSuccess;
             }
-            ok = api->GroupEnd() == ncclSuccess && ok;
-            for (int p = 0; p < P && ok; ++p) {
-                ok = hipSetDevice(shards[p].device) == hipSuccess
-                  && detail::pr_commit_gathered(shards[p].shard, shards[p].r[(iter + 1) & 1], P, stride, longest,
-                                                config->tolerance, shards[p].stream) == hipSuccess;
+            fine = fine
+                && hipMemcpyAsync(&pinned[p][iter & 1], d.shard.d_state, sizeof(detail::PrState), hipMemcpyDeviceToHost, d.stream) == hipSuccess
+                && hipEventRecord(seen[p][iter & 1], d.stream) == hipSuccess;
+            if (fine && iter >= 1) {
+                fine = hipEventSynchronize(seen[p][(iter - 1) & 1]) == hipSuccess;
+                if (fine && pinned[p][(iter - 1) & 1].done) break;
             }
         }
-        if (!ok) break;
-        ok = hipSetDevice(shards[0].device) == hipSuccess
-          && hipMemcpyAsync(&pinned[iter & 1], shards[0].shard.d_state, sizeof(detail::PrState), hipMemcpyDeviceToHost,
-                            shards[0].stream) == hipSuccess
-          && hipEventRecord(seen[iter & 1], shards[0].stream) == hipSuccess;
-        if (ok && iter >= 1) {
-            ok = hipEventSynchronize(seen[(iter - 1) & 1]) == hipSuccess;
-            if (ok && pinned[(iter - 1) & 1].done) break;
+        if (!fine) {
+            // Let nobody wait for this thread: release the rendezvous, and abort the collectives the peers may be
+            // blocked in on the device (a rank that never joins would otherwise hang them).
+            meet.fail();
+            if (api && api->CommAbort) {
+                for (DeviceShard& other : shards) {
+                    if (other.comm) (void)api->CommAbort(other.comm);
+                }
+            }
         }
-    }
-    for (int p = 0; p < P && ok; ++p) {
-        ok = hipSetDevice(shards[p].device) == hipSuccess && hipStreamSynchronize(shards[p].stream) == hipSuccess;
+        fine = hipStreamSynchronize(d.stream) == hipSuccess && fine;
+        return fine;
+    };
+    if (ok) {
+        std::vector<char> outcome(P, 0);
+        if (P == 1) {
+            outcome[0] = drive(0);
+        } else {
+            std::vector<std::thread> threads;
+            for (int p = 0; p < P; ++p) threads.emplace_back([&, p] { outcome[p] = drive(p); });
+            for (std::thread& t : threads) t.join();
+        }
+        for (int p = 0; p < P; ++p) ok = ok && outcome[p];
+        if (!ok) {
+            for (DeviceShard& d : shards) d.comm_aborted = d.comm != nullptr && api && api->CommAbort;
+        }
     }
     if (ok) {
         ok = hipSetDevice(shards[0].device) == hipSuccess
@@ -366,8 +422,10 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
             result = PageRankResult();
         }
     }
-    if (pinned) (void)hipHostFree(pinned);
-    for (hipEvent_t e : seen) if (e) (void)hipEventDestroy(e);
+    for (int p = 0; p < P; ++p) {
+        if (pinned[p]) (void)hipHostFree(pinned[p]);
+        for (hipEvent_t e : seen[p]) if (e) (void)hipEventDestroy(e);
+    }
     release(shards, api);
     (void)hipSetDevice(previous_device);
     (void)hipGetLastError();

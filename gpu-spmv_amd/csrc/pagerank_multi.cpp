@@ -12,9 +12,11 @@
 //     slice carries that device's two partial sums as doubles);
 //   * per iteration, per device: the fused step kernels (direct vector-CSR or the LDS-tiled engine, the
 //     same pr_step the single-GPU loop runs), then ONE in-place ncclAllGather of `stride` floats per device
-//     over xGMI (RCCL, single-process ncclCommInitAll, one stream per device, grouped calls), then
-//     pr_commit_gathered folds the P partial pairs in device order — identical state on every device, no
-//     separate all-reduce;
+//     over xGMI (RCCL, single-process ncclCommInitAll, one stream per device), then pr_commit_gathered folds
+//     the P partial pairs in device order — identical state on every device, no separate all-reduce;
+//   * SPMV_MULTI_GPU_BLOCKS=C > 1: the overlapped exchange — the vector is numbered chunk-major (block c =
+//     piece c of every shard), C all-gathers per step run on a side stream and the tiled engine's phase 1 of
+//     the NEXT step follows them block by block (pr_expand);
 //   * one host thread per device drives its stream (issuing for eight devices from one thread would take about as
 //     long as the step itself); each runs one step ahead of the convergence check (device-side `done` flag,
 //     pinned mirror), as the single-GPU loop does; a failure on any device releases the others
@@ -131,8 +133,10 @@ struct DeviceShard {
     ncclComm_t comm = nullptr;
     bool comm_aborted = false;      // ncclCommAbort already released it
     bool have_header = false;
-    hipEvent_t stepped = nullptr;   // copy exchange: this shard's new slice is complete ...
-    hipEvent_t gathered = nullptr;  // ... and this shard has finished reading its peers' slices
+    hipStream_t side_stream = nullptr;      // overlapped exchange: the collectives / copies run here
+    std::vector<hipEvent_t> block_done;     // ... and block c of the new vector is complete
+    hipEvent_t stepped = nullptr;   // this shard's new slice is complete ...
+    hipEvent_t gathered = nullptr;  // ... copy exchange: and this shard has finished reading its peers' slices
 };
 
 void release(std::vector<DeviceShard>& shards, const Rccl* api) {
@@ -146,7 +150,12 @@ void release(std::vector<DeviceShard>& shards, const Rccl* api) {
                         static_cast<void*>(d.shard.d_state), static_cast<void*>(d.shard.d_block_partials)}) {
             if (p) (void)hipFree(p);
         }
+        if (d.side_stream) {
+            (void)hipStreamSynchronize(d.side_stream);
+            (void)hipStreamDestroy(d.side_stream);
+        }
         if (d.stream) (void)hipStreamDestroy(d.stream);
+        for (hipEvent_t e : d.block_done) if (e) (void)hipEventDestroy(e);
         if (d.stepped) (void)hipEventDestroy(d.stepped);
         if (d.gathered) (void)hipEventDestroy(d.gathered);
     }
@@ -204,13 +213,31 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
     int longest = 0;
     for (int p = 0; p < P; ++p) longest = std::max(longest, bounds[p + 1] - bounds[p]);
     if (longest % 2) ++longest;                                  // 8-byte aligned tails
-    const long long stride = longest + (exchange ? kTail : 0);
-    const long long padded = stride * P;
+    // The vector is a sequence of `blocks` blocks, block c = piece c of every shard back to back (see RowMap in
+    // pagerank_engine.h and Layout in pagerank_dist.py).  One block (default): every shard's slice is contiguous,
+    // one all-gather per step.  SPMV_MULTI_GPU_BLOCKS=C > 1: the overlapped exchange — C all-gathers on a side
+    // stream, the next step's phase 1 for the columns of block c runs while block c + 1 is on the links.
+    int blocks = 1;
+    if (const char* env = std::getenv("SPMV_MULTI_GPU_BLOCKS")) blocks = std::max(1, std::min(16, std::atoi(env)));
+    if (!exchange) blocks = 1;
+    const int tail = exchange ? kTail : 0;
+    long long piece = longest + tail;
+    if (blocks > 1) {
+        const long long align = longest >= (1 << 18) ? 32768 : 4;   // block boundaries = strip boundaries of the tiled engine
+        const long long per_block = (static_cast<long long>(longest) + tail + blocks - 1) / blocks;
+        piece = (per_block + align - 1) / align * align;
+    }
+    const long long block = piece * P;
+    const long long padded = block * blocks;
     if (padded > 0x7fffffffLL) return result;
+    auto place = [&](int owner, long long i) {                   // (shard, row inside it) -> index in the padded vector
+        return static_cast<int>(blocks == 1 ? owner * piece + i : (i / piece) * block + owner * piece + i % piece);
+    };
     auto position = [&](int node) {                              // node -> index in the padded vector
         const int owner = static_cast<int>(std::upper_bound(bounds.begin() + 1, bounds.end() - 1, node) - (bounds.begin() + 1));
-        return static_cast<int>(owner * stride + (node - bounds[owner]));
+        return place(owner, node - bounds[owner]);
     };
+    const long long last_block = (blocks - 1) * block;           // the tails sit at the end of every shard's last piece
 
     // dangling columns exactly as the reference's host scan (src/pagerank.cu:20-48), in padded positions
     std::vector<unsigned char> mask(static_cast<size_t>(padded), 0);
@@ -235,7 +262,7 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
     for (unsigned long long k = 0; k < num_dangling; ++k) first_state.dangling_sum += start;
     std::vector<float> start_vector(static_cast<size_t>(padded), 0.0f);
     for (int p = 0; p < P; ++p) {
-        std::fill_n(start_vector.begin() + p * stride, bounds[p + 1] - bounds[p], start);
+        for (int i = 0; i < bounds[p + 1] - bounds[p]; ++i) start_vector[place(p, i)] = start;
     }
 
     // ---- upload the shards
@@ -257,8 +284,9 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
         }
         ok = hipSetDevice(d.device) == hipSuccess
           && hipStreamCreate(&d.stream) == hipSuccess
-          && (!by_copies || (hipEventCreateWithFlags(&d.stepped, hipEventDisableTiming) == hipSuccess &&
-                             hipEventCreateWithFlags(&d.gathered, hipEventDisableTiming) == hipSuccess))
+          && (blocks == 1 || hipStreamCreate(&d.side_stream) == hipSuccess)
+          && hipEventCreateWithFlags(&d.stepped, hipEventDisableTiming) == hipSuccess
+          && hipEventCreateWithFlags(&d.gathered, hipEventDisableTiming) == hipSuccess
           && hipMalloc(reinterpret_cast<void**>(&d.d_row_ptrs), (static_cast<size_t>(rows) + 1) * sizeof(int)) == hipSuccess
           && hipMalloc(reinterpret_cast<void**>(&d.d_cols), static_cast<size_t>(std::max(local_nnz, 1)) * sizeof(int)) == hipSuccess
           && hipMalloc(reinterpret_cast<void**>(&d.d_vals), static_cast<size_t>(std::max(local_nnz, 1)) * sizeof(float)) == hipSuccess
@@ -282,7 +310,13 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
         d.have_header = true;
         detail::PrShard& sh = d.shard;
         sh.local_rows = rows;
-        sh.map.base = static_cast<int>(p * stride);
+        sh.map.base = static_cast<int>(p * piece);
+        if (blocks > 1) {
+            sh.map.piece = static_cast<int>(piece);
+            sh.map.block = static_cast<int>(block);
+        }
+        d.block_done.assign(blocks > 1 ? blocks : 0, nullptr);
+        for (hipEvent_t& e : d.block_done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         sh.n_global = n;
         sh.nnz = local_nnz;
         sh.d_row_ptrs = d.d_row_ptrs;
@@ -334,28 +368,44 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
             }
             fine = fine && detail::pr_step(d.shard, r_old, r_new, config->damping_factor, detail::PushTargets{}, d.stream) == hipSuccess;
             if (fine && exchange) {      // the two partial sums go into the tail of this device's own slice
-                double* tail = reinterpret_cast<double*>(r_new + p * stride + longest);
-                fine = detail::pr_reduce(d.shard, tail, d.stream) == hipSuccess;
+                double* tail_slot = reinterpret_cast<double*>(r_new + last_block + (p + 1) * piece - kTail);
+                fine = detail::pr_reduce(d.shard, tail_slot, d.stream) == hipSuccess;
             } else if (fine) {
                 fine = detail::pr_reduce_commit(d.shard, config->tolerance, d.stream) == hipSuccess;
             }
-            if (fine && by_copies) {
-                // every shard pulls every peer's slice (tail included) once that peer's step has finished
-                fine = hipEventRecord(d.stepped, d.stream) == hipSuccess;
-                if (!meet.arrive(fine)) { fine = false; break; }
-                for (int q = 0; q < P && fine; ++q) {
-                    if (q == p) continue;
-                    fine = hipStreamWaitEvent(d.stream, shards[q].stepped, 0) == hipSuccess
-                        && hipMemcpyAsync(r_new + q * stride, shards[q].r[(iter + 1) & 1] + q * stride,
-                                          static_cast<size_t>(stride) * sizeof(float), hipMemcpyDeviceToDevice, d.stream) == hipSuccess;
-                }
-                fine = fine && hipEventRecord(d.gathered, d.stream) == hipSuccess;
-                if (!meet.arrive(fine)) { fine = false; break; }
-            } else if (fine && exchange) {
-                fine = api->AllGather(r_new + p * stride, r_new, static_cast<size_t>(stride), ncclFloat, d.comm, d.stream) == ncclSuccess;
-            }
             if (fine && exchange) {
-                fine = detail::pr_commit_gathered(d.shard, r_new, P, stride, longest, config->tolerance, d.stream) == hipSuccess;
+                // The exchange: block by block (one block unless SPMV_MULTI_GPU_BLOCKS), on the side stream when
+                // there are several, so that this stream can multiply block c while block c + 1 travels.
+                const bool side = blocks > 1;
+                hipStream_t xs = side ? d.side_stream : d.stream;
+                if (side || by_copies) fine = hipEventRecord(d.stepped, d.stream) == hipSuccess;
+                if (fine && side) fine = hipStreamWaitEvent(xs, d.stepped, 0) == hipSuccess;
+                if (by_copies && !meet.arrive(fine)) { fine = false; break; }        // every `stepped` is recorded
+                for (int c = 0; c < blocks && fine; ++c) {
+                    float* mine = r_new + c * block;
+                    if (by_copies) {      // pull piece c of every peer (tail included in the last one)
+                        for (int q = 0; q < P && fine; ++q) {
+                            if (q == p) continue;
+                            if (c == 0) fine = hipStreamWaitEvent(xs, shards[q].stepped, 0) == hipSuccess;
+                            fine = fine && hipMemcpyAsync(mine + q * piece, shards[q].r[(iter + 1) & 1] + c * block + q * piece,
+                                                          static_cast<size_t>(piece) * sizeof(float), hipMemcpyDeviceToDevice, xs) == hipSuccess;
+                        }
+                    } else {
+                        fine = api->AllGather(mine + p * piece, mine, static_cast<size_t>(piece), ncclFloat, d.comm, xs) == ncclSuccess;
+                    }
+                    if (fine && side) {
+                        fine = hipEventRecord(d.block_done[c], xs) == hipSuccess
+                            && hipStreamWaitEvent(d.stream, d.block_done[c], 0) == hipSuccess;
+                        // head start on the next step: the columns of the blocks that have arrived
+                        if (fine && c + 1 < blocks) fine = detail::pr_expand(d.shard, r_new, static_cast<long long>(c + 1) * block, d.stream) == hipSuccess;
+                    }
+                }
+                if (by_copies) {
+                    fine = fine && hipEventRecord(d.gathered, xs) == hipSuccess;
+                    if (!meet.arrive(fine)) { fine = false; break; }                 // every `gathered` is recorded
+                }
+                fine = fine && detail::pr_commit_gathered(d.shard, r_new + last_block, P, piece, piece - kTail, config->tolerance,
+                                                          d.stream) == hipSuccess;
             }
             fine = fine
                 && hipMemcpyAsync(&pinned[p][iter & 1], d.shard.d_state, sizeof(detail::PrState), hipMemcpyDeviceToHost, d.stream) == hipSuccess
@@ -376,6 +426,7 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
             }
         }
         fine = hipStreamSynchronize(d.stream) == hipSuccess && fine;
+        if (d.side_stream) fine = hipStreamSynchronize(d.side_stream) == hipSuccess && fine;
         return fine;
     };
     if (ok) {
@@ -404,13 +455,13 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
         result.converged = last_state.converged != 0;
         result.ranks = new float[n];
         const float* last = shards[0].r[last_state.iterations & 1];
-        if (exchange) {
-            for (int p = 0; p < P && ok; ++p) {
-                ok = hipMemcpy(result.ranks + bounds[p], last + p * stride, static_cast<size_t>(bounds[p + 1] - bounds[p]) * sizeof(float),
+        for (int p = 0; p < P && ok; ++p) {               // every shard's rows, piece by piece
+            const long long rows = bounds[p + 1] - bounds[p];
+            for (long long done = 0; done < rows && ok; done += piece) {
+                const long long count = std::min<long long>(piece, rows - done);
+                ok = hipMemcpy(result.ranks + bounds[p] + done, last + place(p, done), static_cast<size_t>(count) * sizeof(float),
                                hipMemcpyDeviceToHost) == hipSuccess;
             }
-        } else {
-            ok = hipMemcpy(result.ranks, last, static_cast<size_t>(n) * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
         }
         if (ok) {
             double total = 0.0;

@@ -7,7 +7,9 @@
 //                                     and on a power-law graph, plain and through SPMV_NUM_GPUS; with N == 1 the
 //                                     collective path is exercised too (SPMV_MULTI_GPU_FORCE_RCCL), and the P > 1
 //                                     partition / layout / commit with 2, 3 and 8 shards sharing the device
-//                                     (SPMV_MULTI_GPU_SHARE_DEVICES: slices exchanged by device copies)
+//                                     (SPMV_MULTI_GPU_SHARE_DEVICES: slices exchanged by device copies), also with
+//                                     the overlapped exchange (SPMV_MULTI_GPU_BLOCKS) on a graph large enough for
+//                                     the tiled engine, whose phase 1 then follows the blocks
 // Plain host C++: g++ -Iinclude ... -lspmv_amd.
 #include "spmv/pagerank.h"
 #include "spmv/spmv.h"
@@ -44,9 +46,10 @@ static CSRMatrix* make_graph(const std::vector<int>& lens, unsigned seed) {
         m->row_ptrs[r] = at;
         std::vector<int> cols;
         while (static_cast<int>(cols.size()) < lens[r]) {
-            int c = static_cast<int>(rng() % n);
-            if (c % 97 == 5) continue;                      // dangling nodes: nobody links to them
-            cols.push_back(c);
+            for (int missing = lens[r] - static_cast<int>(cols.size()); missing > 0; --missing) {
+                const int c = static_cast<int>(rng() % n);
+                if (c % 97 != 5) cols.push_back(c);         // dangling nodes: nobody links to them
+            }
             std::sort(cols.begin(), cols.end());
             cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
         }
@@ -82,11 +85,49 @@ static void test_bounds() {
     for (int p = 0; p < 8; ++p) EXPECT(eight[p + 1] - eight[p] == 125);
 }
 
+// the overlapped exchange: blocks of the chunk-major vector, on the side stream, head starts of phase 1
+static void test_blocks() {
+    std::vector<int> lens(700000, 6);                       // 4.2 M entries: both halves run on the tiled engine
+    for (int i = 0; i < 3000; ++i) lens[i * 200] = 3000;    // and some rows long enough for the direct path
+    CSRMatrix* g = make_graph(lens, 99u);
+    const int n = g->num_rows;
+    EXPECT(csr_to_gpu(g) == 0);
+    PageRankConfig cfg;
+    cfg.max_iterations = 12;                                // fixed work: equal iteration counts by construction
+    cfg.tolerance = 0.0f;
+    PageRankResult single = pagerank(g, &cfg);
+    EXPECT(single.ranks && single.iterations == 12);
+    setenv("SPMV_MULTI_GPU_SHARE_DEVICES", "1", 1);
+    for (int blocks : {1, 3, 4}) {
+        char text[16];
+        std::snprintf(text, sizeof(text), "%d", blocks);
+        setenv("SPMV_MULTI_GPU_BLOCKS", text, 1);
+        for (int shards : {2, 3}) {
+            PageRankResult r = pagerank_multi_gpu(g, &cfg, shards);
+            EXPECT(r.ranks != nullptr && r.iterations == 12);
+            if (r.ranks) EXPECT(worst_relative(r, single, n) <= 4e-6);
+            pagerank_free(&r);
+        }
+    }
+    unsetenv("SPMV_MULTI_GPU_SHARE_DEVICES");
+    setenv("SPMV_MULTI_GPU_FORCE_RCCL", "1", 1);            // RCCL with one rank, two blocks, side stream
+    setenv("SPMV_MULTI_GPU_BLOCKS", "2", 1);
+    PageRankResult forced = pagerank_multi_gpu(g, &cfg, 1);
+    EXPECT(forced.ranks != nullptr && forced.iterations == 12);
+    if (forced.ranks) EXPECT(worst_relative(forced, single, n) <= 4e-6);
+    pagerank_free(&forced);
+    unsetenv("SPMV_MULTI_GPU_FORCE_RCCL");
+    unsetenv("SPMV_MULTI_GPU_BLOCKS");
+    pagerank_free(&single);
+    csr_destroy(g);
+}
+
 static void test_run(int gpus) {
     std::vector<int> uniform(20000, 8);
     std::vector<int> skewed(20000);
     for (int i = 0; i < 20000; ++i) skewed[i] = 2 + 4000 / (i + 1);       // power-law-ish: the first rows are long
     int which = 0;
+    if (gpus == 1) test_blocks();
     for (const std::vector<int>& lens : {uniform, skewed}) {
         CSRMatrix* g = make_graph(lens, 7u + which++);
         const int n = g->num_rows;

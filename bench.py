@@ -57,6 +57,12 @@ def csr_bytes(rows, cols, nnz):
 
 def main():
     args = parse()
+    # The contract: stdout carries exactly ONE line, the JSON.  Libraries write there too (RCCL prints a version
+    # banner on stdout when a communicator is created), so file descriptor 1 is pointed at stderr for the run and
+    # the line goes out through a private duplicate of the real stdout.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -82,8 +88,14 @@ def main():
     spmv.lib().spmv_c_set_device(dev_index)
     spmv.require_gpu()
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # SPMV_BENCH_FORCE_EXCHANGE=1 with one rank: tails, collectives and the exchange trials stay in the loop
+    # (a rehearsal of the N > 1 code path on the real backend; the number it prints is not the N = 1 number)
+    force_exchange = world == 1 and os.environ.get("SPMV_BENCH_FORCE_EXCHANGE", "0") == "1"
+    if world > 1 or force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -98,7 +110,7 @@ def main():
 
     n, k = args.rows, args.nnz_per_row
     nnz_total = n * k
-    layout = prd.Layout(n, world, rank)
+    layout = prd.Layout(n, world, rank, exchange=True if force_exchange else None)
     shard_len, row_begin, local_rows = layout.shard_len, layout.row_begin, layout.local_rows
 
     # ---- build this rank's rows in HBM (torch owns the memory; the C ABI fills it) ----
@@ -111,12 +123,12 @@ def main():
     assert status == 0, spmv.spmv_error_string(status)
     counts = torch.zeros(n, dtype=torch.int32, device=device)
     spmv.lib().spmv_c_count_columns(local_rows * k, cols.data_ptr(), n, counts.data_ptr(), stream)
-    if world > 1:
+    if world > 1 or force_exchange:
         dist.all_reduce(counts)
     spmv.lib().spmv_c_reciprocal_values(local_rows * k, cols.data_ptr(), counts.data_ptr(), vals.data_ptr(), stream)
     del counts
     cols_v, vals_v = cols[: local_rows * k], vals[: local_rows * k]
-    if world > 1:
+    if layout.exchange:
         cols_v.copy_(layout.remap_columns(cols_v))     # node ids -> positions in the padded rank vector
 
     engine = prd.HipEngine(row_ptrs, cols_v, vals_v, layout)
@@ -132,11 +144,11 @@ def main():
     # line of the gather run is already printed (see the end of main), so nothing it does can lose that line.
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
-    exchange = "none" if world == 1 else "gather"
+    exchange = "gather" if layout.exchange else "none"
     pr.mode = "gather"
 
     def timed(loop, its_engine):
@@ -153,7 +165,7 @@ def main():
             step += 1
         barrier()
         seconds = time.perf_counter() - t0
-        if world > 1:
+        if world > 1 or force_exchange:
             t = torch.tensor([seconds], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             seconds = float(t.item())
@@ -172,7 +184,7 @@ def main():
     # SPMV_PR_OVERLAP=<C>[,<C>...] sets the block counts to try (default 4,2).
     candidates = [int(c) for c in os.environ.get("SPMV_PR_OVERLAP", "4,2").split(",") if c.strip()]
     candidates = [c for c in candidates if c > 1]
-    if world > 1 and candidates:
+    if layout.exchange and candidates:
         def after(loop, steps):
             loop.reset()
             for i in range(steps):
@@ -183,7 +195,7 @@ def main():
         exchange_trials = {"gather_ms_per_step": round(elapsed / args.steps * 1e3, 4), "overlapped": []}
         best = (elapsed, engine, pr, layout, cols_v, exchange)
         for blocks in candidates:
-            lay2 = prd.Layout(n, world, rank, chunks=blocks)
+            lay2 = prd.Layout(n, world, rank, chunks=blocks, exchange=True)
             cols2 = torch.empty_like(cols)
             scratch_ptrs, scratch_vals = torch.empty_like(row_ptrs), torch.empty_like(vals)
             status = spmv.lib().spmv_c_gen_uniform_rows(args.seed, row_begin, local_rows, n, k, scratch_ptrs.data_ptr(),
@@ -348,12 +360,13 @@ def main():
         pr_f.close()
 
     if rank == 0:
-        print(json.dumps(result), flush=True)      # before teardown: the line is out whatever happens next
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())    # before teardown: the line is out whatever happens next
     if world > 1 and os.environ.get("SPMV_PR_EXCHANGE", "gather") in ("push", "auto"):
         push_trial(pr, dist, torch, device, world, rank, backend, damping, never, barrier, ms_per_step)
     engine.close()
     pr.close()          # unmaps peers, barriers, then frees the rank vectors
-    if world > 1:
+    if world > 1 or force_exchange:
         dist.destroy_process_group()
 
 

@@ -71,8 +71,12 @@ class Layout:
     pieces are rounded up to `align` columns so that block boundaries are strip boundaries of the tiled engine.
     The last TAIL floats of a rank's last piece carry its two partial sums (as doubles) in either form."""
 
-    def __init__(self, n: int, world: int = 1, rank: int = 0, bounds=None, chunks: int = 1, align: int = None):
+    def __init__(self, n: int, world: int = 1, rank: int = 0, bounds=None, chunks: int = 1, align: int = None,
+                 exchange: bool = None):
         self.n, self.world, self.rank = n, world, rank
+        # exchange=True with world == 1 keeps tails, blocks and collectives in the loop although there is nobody to
+        # exchange with: the whole multi-rank code path on one device (how the RCCL calls are tested on a 1-GPU box)
+        self.exchange = world > 1 if exchange is None else bool(exchange)
         if bounds is None:
             shard_len = (n + world - 1) // world
             if world > 1 and shard_len % 2:
@@ -85,8 +89,10 @@ class Layout:
             shard_len = int(np.diff(self.bounds).max()) if world > 0 else n
             if world > 1 and shard_len % 2:
                 shard_len += 1
-        tail = TAIL if world > 1 else 0
-        self.chunks = max(1, int(chunks)) if world > 1 else 1
+        if self.exchange and shard_len % 2:
+            shard_len += 1
+        tail = TAIL if self.exchange else 0
+        self.chunks = max(1, int(chunks)) if self.exchange else 1
         if self.chunks == 1:
             self.piece = shard_len + tail
         else:
@@ -133,7 +139,7 @@ class Layout:
 
     def remap_columns(self, cols):
         """Column (= node) indices -> positions in the padded vector (numpy or torch int32)."""
-        if self.world == 1:
+        if not self.exchange:
             return cols
         owner = self.owner_of(cols)
         if isinstance(cols, torch.Tensor):
@@ -144,7 +150,7 @@ class Layout:
     def positions(self) -> np.ndarray:
         """Padded position of every node 0..n-1."""
         g = np.arange(self.n, dtype=np.int64)
-        if self.world == 1:
+        if not self.exchange:
             return g
         owner = np.searchsorted(self.bounds[1:-1], g, side="right")
         return self._place(owner, g - self.bounds[:-1][owner])
@@ -339,6 +345,7 @@ class ShardedPageRank:
         # overlapped exchange: the collectives are issued from a side stream so that the compute stream is
         # free to multiply block c while block c + 1 is still on the links
         self._comm = torch.cuda.Stream(self.device) if self.device.type == "cuda" and layout.chunks > 1 else None
+        assert layout.exchange or layout.world == 1
 
     def _device_vector(self, count):
         ptr = c_void_p(None)
@@ -479,7 +486,7 @@ class ShardedPageRank:
     def iterate(self, k, damping, tolerance):
         """Enqueue iteration k (0-based): r[k & 1] -> r[(k + 1) & 1]."""
         r_old, r_new = self.r[k & 1], self.r[(k + 1) & 1]
-        if self.world == 1:
+        if not self.layout.exchange:
             if hasattr(self.engine, "step_and_commit"):
                 self.engine.step_and_commit(r_old, r_new, damping, tolerance)
             else:

@@ -316,6 +316,53 @@ def test_head_start_on_a_chunk_major_vector(gpu, oracle, chunks, align, skewed):
         sp.engine.close()
 
 
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_exchange_loop_through_rccl_with_one_rank(gpu, oracle, chunks):
+    """The one-process-per-GPU loop on the REAL backend (torch.distributed "nccl" = RCCL) with a single rank:
+    Layout(exchange=True) keeps tails, blocks and collectives in the loop although there is nobody to exchange
+    with, so the in-place all_gather_into_tensor on the library's own device memory, the async collectives on
+    the side stream, Work.wait() ordering and the head starts all run exactly as they do with eight ranks —
+    only the data movement between devices is missing.  Result = the plain single-rank loop's."""
+    torch = pytest.importorskip("torch")
+    import socket
+    import torch.distributed as dist
+    prd = importlib.import_module("gpu-spmv_amd.pagerank_dist")
+    n = 400_000
+    rp, ci, va = graph(gpu, n, 8, 41, dangling=(9, 123_456))
+    dev = torch.device("cuda:0")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    try:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    except Exception as exc:                                   # noqa: BLE001 - no RCCL in this environment
+        pytest.skip("RCCL process group unavailable: %r" % (exc,))
+    try:
+        def loop(lay):
+            d_ci = torch.from_numpy(ci).to(dev)
+            d_ci = lay.remap_columns(d_ci).to(torch.int32).contiguous()
+            eng = prd.HipEngine(torch.from_numpy(rp).to(dev), d_ci, torch.from_numpy(va).to(dev), lay)
+            return prd.ShardedPageRank(eng, lay).prepare()
+        plain = loop(prd.Layout(n))
+        want_ranks, want_iters, _, want_conv = plain.run(0.85, 1e-6, 100, check_every=2)
+        lay = prd.Layout(n, 1, 0, chunks=chunks, exchange=True)
+        assert lay.exchange and lay.chunks == chunks and lay.padded >= n + 4
+        through = loop(lay)
+        assert gpu.csr_has_tiled_plan(through.engine._A)
+        got_ranks, got_iters, _, got_conv = through.run(0.85, 1e-6, 100, check_every=2)
+        assert got_conv == want_conv and got_iters == want_iters
+        assert np.max(np.abs(got_ranks.astype(np.float64) - want_ranks) / want_ranks) <= 2e-6
+        want, iters, _, conv = oracle.pagerank(rp, ci, va, num_cols=n, wide_sums=True)
+        if iters != got_iters:
+            want, *_ = oracle.pagerank(rp, ci, va, num_cols=n, tolerance=0.0, max_iterations=got_iters, wide_sums=True)
+        compare(got_ranks, want)
+        for sp in (plain, through):
+            sp.engine.close()
+            sp.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_a_shard_keeps_its_plan_when_the_side_table_replaces_it(gpu, oracle):
     """Two engines over the SAME row-pointer array but different column arrays (bench.py builds the plain and the
     chunk-major numbering of one shard that way): the side table is keyed by the row pointers, so the second

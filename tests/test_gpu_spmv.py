@@ -256,7 +256,9 @@ def run_tiled(spmv, rp, ci, va, cols, x, kernel=1, x_offset=0):
 
 
 @pytest.mark.parametrize("rows,cols,k", [(300_000, 400_000, 8), (131_073, 1_000_003, 9), (2_500_000, 270_000, 2),
-                                         (150_000, 2_000_000, 16), (100_000, 3_000_000, 12)])   # last two: wide shards (16K / 32K strips)
+                                         (150_000, 2_000_000, 16), (100_000, 3_000_000, 12),    # wide shards (16K / 32K strips)
+                                         (200_000, 60_000_000, 12),         # 1832 strips: the builder's one-workgroup-per-CU LDS shape
+                                         (100_000, 3072 * 32768, 12)])      # 3072 strips: the most the engine takes
 def test_tiled_engine_uniform(gpu, oracle, rows, cols, k):
     """x through LDS strips (use_texture): shapes not multiples of the strip / tile sizes."""
     rp, ci, va = gpu.synth.uniform_csr(42, 0, rows, cols, k)

@@ -33,6 +33,10 @@ void release(CsrAux* a) {
     if (a->d_tile_rows) (void)hipFree(a->d_tile_rows);
     if (a->d_carry_row) (void)hipFree(a->d_carry_row);
     if (a->d_carry_val) (void)hipFree(a->d_carry_val);
+    for (const CsrAux::MergeCarry& c : a->extra_carry) {
+        if (c.row) (void)hipFree(c.row);
+        if (c.val) (void)hipFree(c.val);
+    }
     a->tiled.reset();        // (users still holding the plan keep it alive)
     delete a;
 }
@@ -75,6 +79,14 @@ TraceRange::TraceRange(const char* name) : open_(false) {
 
 TraceRange::~TraceRange() {
     if (open_) (void)roctx().pop();
+}
+
+hipError_t malloc_any_time(void** ptr, size_t bytes) {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    const bool switched = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+    const hipError_t e = hipMalloc(ptr, bytes);
+    if (switched) (void)hipThreadExchangeStreamCaptureMode(&mode);
+    return e;
 }
 
 void PrWorkspace::release() {

@@ -10,6 +10,8 @@
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <mutex>
+#include <vector>
 
 namespace spmv {
 namespace detail {
@@ -54,9 +56,19 @@ struct CsrAux {
     int*   d_tile_rows = nullptr;    // [num_tiles + 1]
     int    num_tiles = 0;
     int    tile_items = 0;
-    // merge-path carry-out slots
+    // merge-path carry-out slots: written by every call, so they belong to the first stream that uses them;
+    // a call on another stream gets its own pair (extra_carry), like the tiled plan's product stream
     int*   d_carry_row = nullptr;    // [num_tiles]
     float* d_carry_val = nullptr;    // [num_tiles]
+    struct MergeCarry {
+        hipStream_t stream;
+        int* row;
+        float* val;
+    };
+    std::mutex merge_lock;           // guards the fields below and the tile + fix-up pair of launches
+    bool carry_taken = false;
+    hipStream_t carry_stream = nullptr;
+    std::vector<MergeCarry> extra_carry;
     // LDS-tiled engine: bucketed copy of the entries, built on first use (tiled.h)
     std::shared_ptr<TiledPlan> tiled;
     bool tiled_failed = false;       // build failed once (e.g. out of memory): do not retry
@@ -110,6 +122,11 @@ struct EventPair {
 EventPair& thread_events();
 
 hipStream_t current_stream();
+
+// hipMalloc that is also legal while some stream of this thread is being captured into a hipGraph (the
+// thread's capture mode is switched to "relaxed" around the call): per-stream scratch is allocated at a
+// stream's first call on a matrix, and that first call may well be the one a graph capture records.
+hipError_t malloc_any_time(void** ptr, size_t bytes);
 
 // roctx range around a host-side phase (plan build, dispatch, PageRank step): shows up under
 // `rocprofv3 --marker-trace`, costs two indirect calls when a profiler has loaded the roctx library and

@@ -537,7 +537,7 @@ hipError_t launch_csr_vector(const CSRMatrix* A, const float* d_x, float* d_y,
 }
 
 // the tile table of the merge-path kernels: built on first use (or ahead of a timed call), cached with the matrix
-hipError_t prepare_csr_merge(const CSRMatrix* A, CsrAux* aux, hipStream_t s) {
+static hipError_t prepare_csr_merge_locked(const CSRMatrix* A, CsrAux* aux, hipStream_t s) {
     const long long total = static_cast<long long>(A->num_rows) + A->nnz;
     const int num_tiles = static_cast<int>((total + kMergeTile - 1) / kMergeTile);
     if (num_tiles == 0 || !aux) return hipSuccess;
@@ -545,6 +545,12 @@ hipError_t prepare_csr_merge(const CSRMatrix* A, CsrAux* aux, hipStream_t s) {
     if (aux->d_tile_rows) (void)hipFree(aux->d_tile_rows);
     if (aux->d_carry_row) (void)hipFree(aux->d_carry_row);
     if (aux->d_carry_val) (void)hipFree(aux->d_carry_val);
+    for (const CsrAux::MergeCarry& c : aux->extra_carry) {
+        if (c.row) (void)hipFree(c.row);
+        if (c.val) (void)hipFree(c.val);
+    }
+    aux->extra_carry.clear();
+    aux->carry_taken = false;
     aux->d_tile_rows = nullptr;
     aux->d_carry_row = nullptr;
     aux->d_carry_val = nullptr;
@@ -556,10 +562,18 @@ hipError_t prepare_csr_merge(const CSRMatrix* A, CsrAux* aux, hipStream_t s) {
     merge_partition_kernel<<<(num_tiles + 1 + kBlock - 1) / kBlock, kBlock, 0, s>>>(
         A->num_rows, A->nnz, A->d_row_ptrs, num_tiles, aux->d_tile_rows);
     e = hipGetLastError();
+    // the table is read by calls on ANY stream from now on: finish it before it is announced (once per matrix)
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return e;
     aux->num_tiles = num_tiles;
     aux->tile_items = kMergeTile;
     return hipSuccess;
+}
+
+hipError_t prepare_csr_merge(const CSRMatrix* A, CsrAux* aux, hipStream_t s) {
+    if (!aux) return hipSuccess;
+    std::lock_guard<std::mutex> guard(aux->merge_lock);
+    return prepare_csr_merge_locked(A, aux, s);
 }
 
 hipError_t launch_csr_merge(const CSRMatrix* A, CsrAux* aux, const float* d_x, float* d_y,
@@ -567,17 +581,48 @@ hipError_t launch_csr_merge(const CSRMatrix* A, CsrAux* aux, const float* d_x, f
     const long long total = static_cast<long long>(A->num_rows) + A->nnz;
     const int num_tiles = static_cast<int>((total + kMergeTile - 1) / kMergeTile);
     if (num_tiles == 0) return hipSuccess;
-    hipError_t prepared = prepare_csr_merge(A, aux, s);
+    // (the lock also keeps the tile + fix-up pair of one call together when two host threads share a stream)
+    std::lock_guard<std::mutex> guard(aux->merge_lock);
+    hipError_t prepared = prepare_csr_merge_locked(A, aux, s);
     if (prepared != hipSuccess) return prepared;
+
+    // the carry-out slots of THIS stream
+    int* carry_row = nullptr;
+    float* carry_val = nullptr;
+    if (!aux->carry_taken) {
+        aux->carry_taken = true;
+        aux->carry_stream = s;
+    }
+    if (aux->carry_stream == s) {
+        carry_row = aux->d_carry_row;
+        carry_val = aux->d_carry_val;
+    } else {
+        for (const CsrAux::MergeCarry& c : aux->extra_carry) {
+            if (c.stream == s) {
+                carry_row = c.row;
+                carry_val = c.val;
+            }
+        }
+        if (!carry_row) {
+            CsrAux::MergeCarry fresh{s, nullptr, nullptr};
+            if (malloc_any_time(reinterpret_cast<void**>(&fresh.row), num_tiles * sizeof(int)) != hipSuccess ||
+                malloc_any_time(reinterpret_cast<void**>(&fresh.val), num_tiles * sizeof(float)) != hipSuccess) {
+                if (fresh.row) (void)hipFree(fresh.row);
+                return hipErrorOutOfMemory;
+            }
+            aux->extra_carry.push_back(fresh);
+            carry_row = fresh.row;
+            carry_val = fresh.val;
+        }
+    }
 
     merge_tile_kernel<<<num_tiles, kBlock, 0, s>>>(A->num_rows, A->nnz, A->d_row_ptrs,
                                                    A->d_col_indices, A->d_values, d_x,
-                                                   aux->d_tile_rows, d_y,
-                                                   aux->d_carry_row, aux->d_carry_val);
+                                                   aux->d_tile_rows, d_y, carry_row, carry_val);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     merge_fixup_kernel<<<(num_tiles + kBlock - 1) / kBlock, kBlock, 0, s>>>(
-        A->num_rows, num_tiles, aux->d_carry_row, aux->d_carry_val, d_y);
+        A->num_rows, num_tiles, carry_row, carry_val, d_y);
     return hipGetLastError();
 }
 

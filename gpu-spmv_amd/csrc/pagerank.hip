@@ -537,6 +537,7 @@ public:
         else ws_->busy = false;
     }
     detail::PrWorkspace* operator->() { return ws_; }
+    bool is_private() const { return private_; }
 
     bool ensure(size_t len, size_t partial_count) {
         detail::PrWorkspace& w = *ws_;
@@ -620,9 +621,13 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     // first step; otherwise the loop starts on the direct kernel and builds the plan only once it has
     // spent about one build's worth of time on direct steps (ski rental: never more than ~2x the better
     // choice).  Estimates per stored entry, measured on C5: build 50 ps, direct step 17 ps, tiled step 3.3 ps.
-    detail::PlanRef plan = detail::tiled_plan_if_cached(adj);
+    // The matrix's workspace goes to one call at a time; a second call running concurrently on the same matrix
+    // gets a private one — and stays on the direct kernels, because a step through the tiled engine is two
+    // launches around the plan's product stream and two loops interleaving on one stream would mix them up.
+    WorkspaceLease ws(adj);
+    detail::PlanRef plan = ws.is_private() ? detail::PlanRef() : detail::tiled_plan_if_cached(adj);
     int build_plan_at = -1;
-    if (!plan && detail::tiled_eligible(adj)) {
+    if (!plan && !ws.is_private() && detail::tiled_eligible(adj)) {
         build_plan_at = static_cast<int>(std::ceil(50.0 / (17.0 - 3.3)));            // = 4 direct steps
         if (const char* env = std::getenv("SPMV_PR_PLAN_AFTER")) build_plan_at = std::max(0, std::atoi(env));
         if (build_plan_at == 0) plan = detail::tiled_plan_for(adj, stream);
@@ -643,7 +648,6 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
         detail::tiled_shape_for(n, adj->num_cols, adj->nnz, &w, &r);
         if (r > 0) partial_pairs = std::max(partial_pairs, (n + r - 1) / r);
     }
-    WorkspaceLease ws(adj);
     if (!ws.ensure(len, std::max<size_t>(2 * static_cast<size_t>(partial_pairs), detail::kNormaliseBlocks))) return result;
     shard.d_dangling = ws->mask;
     shard.d_state = static_cast<PrState*>(ws->state);

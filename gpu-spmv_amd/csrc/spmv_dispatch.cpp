@@ -68,7 +68,8 @@ hipError_t enqueue_csr(const CSRMatrix* A, const float* d_x, float* d_y,
     if (config->use_texture && (config->kernel_type == SpMVConfig::VECTOR_CSR ||
                                 config->kernel_type == SpMVConfig::MERGE_PATH)) {
         if (const PlanRef plan = tiled_plan_for(A, stream)) {
-            return tiled_spmv(*plan, d_x, d_y, stream);
+            const hipError_t e = tiled_spmv(*plan, d_x, d_y, stream);
+            if (e != hipErrorOutOfMemory) return e;     // (no scratch for yet another stream: the direct kernels below)
         }
     }
 
@@ -121,7 +122,10 @@ hipError_t enqueue_ell(const ELLMatrix* A, const float* d_x, float* d_y, const S
     if (A->max_nnz_per_row == 0) return launch_fill_zero(d_y, A->num_rows, stream);
     // use_texture: x through LDS tiles (gives up the default kernel's CPU summation order)
     if (config->use_texture) {
-        if (const PlanRef plan = tiled_plan_for(A, stream)) return tiled_spmv(*plan, d_x, d_y, stream);
+        if (const PlanRef plan = tiled_plan_for(A, stream)) {
+            const hipError_t e = tiled_spmv(*plan, d_x, d_y, stream);
+            if (e != hipErrorOutOfMemory) return e;
+        }
     }
     return launch_ell(A, d_x, d_y, stream);
 }

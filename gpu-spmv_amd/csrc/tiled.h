@@ -7,6 +7,8 @@
 #include "internal.h"
 
 #include <cstdint>
+#include <mutex>
+#include <vector>
 
 namespace spmv {
 namespace detail {
@@ -54,6 +56,21 @@ struct TiledPlan {
     const float* csr_vals = nullptr;
     long long    csr_nnz = 0;
 
+    // Scratch per stream.  `prod` / `long_sums` above are written by every call, so they belong to ONE stream: the
+    // first that runs the plan.  A call on another stream gets its own pair (allocated on first use, kept with
+    // the plan), so asynchronous calls on one matrix from different streams do not share a product stream — the
+    // reference's kernels are stateless and its callers may rely on that.
+    struct StreamScratch {
+        hipStream_t stream;
+        float* prod;
+        float* long_sums;
+    };
+    mutable std::mutex scratch_lock;
+    mutable std::mutex launch_lock;     // held across the two launches of one SpMV
+    mutable bool primary_taken = false;
+    mutable hipStream_t primary_stream = nullptr;
+    mutable std::vector<StreamScratch> extra_scratch;
+
     // what the build cost (reported by bench.py)
     double    build_ms = 0.0;       // host wall clock of the build, allocations and syncs included
     long long plan_bytes = 0;       // device memory the plan holds
@@ -72,7 +89,7 @@ hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s);
 hipError_t tiled_build(const ELLMatrix* A, TiledPlan** out, hipStream_t s);   // from the ELL slabs (no long-row path)
 void tiled_free(TiledPlan* plan);
 
-// y = A x
+// y = A x.  hipErrorOutOfMemory: no scratch for this (additional) stream — the caller may use another kernel.
 hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipStream_t s);
 
 // PageRank step on the same plan, in two parts.

@@ -1219,61 +1219,98 @@ void choose_shape(long long num_rows, long long num_cols, long long nnz, int* st
     *tile_rows = r;
 }
 
+// the product stream and the long-row chunk sums a call on stream `s` writes (see TiledPlan::StreamScratch)
+struct Scratch {
+    float* prod;
+    float* long_sums;
+};
+constexpr size_t kMaxExtraScratch = 7;
+
+hipError_t scratch_for(const TiledPlan& plan, hipStream_t s, Scratch* out) {
+    std::lock_guard<std::mutex> guard(plan.scratch_lock);
+    if (!plan.primary_taken) {
+        plan.primary_taken = true;
+        plan.primary_stream = s;
+    }
+    if (plan.primary_stream == s) {
+        *out = Scratch{plan.prod, plan.long_sums};
+        return hipSuccess;
+    }
+    for (const TiledPlan::StreamScratch& e : plan.extra_scratch) {
+        if (e.stream == s) {
+            *out = Scratch{e.prod, e.long_sums};
+            return hipSuccess;
+        }
+    }
+    if (plan.extra_scratch.size() >= kMaxExtraScratch) return hipErrorOutOfMemory;
+    TiledPlan::StreamScratch fresh{s, nullptr, nullptr};
+    if (malloc_any_time(reinterpret_cast<void**>(&fresh.prod), static_cast<size_t>(plan.nnz + 8) * sizeof(float)) != hipSuccess ||
+        malloc_any_time(reinterpret_cast<void**>(&fresh.long_sums),
+                        static_cast<size_t>(std::max(plan.num_long_chunks, 1)) * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (fresh.prod) (void)hipFree(fresh.prod);
+        return hipErrorOutOfMemory;
+    }
+    plan.extra_scratch.push_back(fresh);
+    *out = Scratch{fresh.prod, fresh.long_sums};
+    return hipSuccess;
+}
+
 // phase 1 for the items [first_item, first_item + num_items) and, with_long, the long-row chunks
 template <int W, int BLOCK>
-hipError_t launch_expand_as(const TiledPlan& plan, int first_item, int num_items, bool with_long, const float* d_x,
-                            const PrState* d_state, hipStream_t s) {
+hipError_t launch_expand_as(const TiledPlan& plan, const Scratch& sc, int first_item, int num_items, bool with_long,
+                            const float* d_x, const PrState* d_state, hipStream_t s) {
     const int chunks = with_long ? plan.num_long_chunks : 0;
-    const LongRows lr{plan.long_chunks, chunks, plan.csr_nnz, plan.csr_cols, plan.csr_vals, plan.long_sums};
+    const LongRows lr{plan.long_chunks, chunks, plan.csr_nnz, plan.csr_cols, plan.csr_vals, sc.long_sums};
     const int long_blocks = xcd_grid((chunks + BLOCK / 64 - 1) / (BLOCK / 64));
     const int grid = long_blocks + xcd_grid(num_items);
     if (grid == 0) return hipSuccess;
     if (plan.col_weight) {
         tiled_expand_kernel<W, BLOCK, true><<<grid, BLOCK, 0, s>>>(
-            plan.items, first_item, num_items, long_blocks, nullptr, plan.a_lcol, plan.col_weight, d_x, plan.num_cols, plan.prod, lr, d_state);
+            plan.items, first_item, num_items, long_blocks, nullptr, plan.a_lcol, plan.col_weight, d_x, plan.num_cols, sc.prod, lr, d_state);
     } else {
         tiled_expand_kernel<W, BLOCK, false><<<grid, BLOCK, 0, s>>>(
-            plan.items, first_item, num_items, long_blocks, plan.a_val, plan.a_lcol, nullptr, d_x, plan.num_cols, plan.prod, lr, d_state);
+            plan.items, first_item, num_items, long_blocks, plan.a_val, plan.a_lcol, nullptr, d_x, plan.num_cols, sc.prod, lr, d_state);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_expand(const TiledPlan& plan, int first_item, int num_items, bool with_long, const float* d_x,
-                         const PrState* d_state, hipStream_t s) {
+hipError_t launch_expand(const TiledPlan& plan, const Scratch& sc, int first_item, int num_items, bool with_long,
+                         const float* d_x, const PrState* d_state, hipStream_t s) {
     switch (plan.strip_cols) {
-        case 4096:  return launch_expand_as<4096, 512>(plan, first_item, num_items, with_long, d_x, d_state, s);
-        case 8192:  return launch_expand_as<8192, 512>(plan, first_item, num_items, with_long, d_x, d_state, s);
-        case 16384: return launch_expand_as<16384, 512>(plan, first_item, num_items, with_long, d_x, d_state, s);
-        default:    return launch_expand_as<32768, 1024>(plan, first_item, num_items, with_long, d_x, d_state, s);   // 128 KiB of LDS: one workgroup per CU
+        case 4096:  return launch_expand_as<4096, 512>(plan, sc, first_item, num_items, with_long, d_x, d_state, s);
+        case 8192:  return launch_expand_as<8192, 512>(plan, sc, first_item, num_items, with_long, d_x, d_state, s);
+        case 16384: return launch_expand_as<16384, 512>(plan, sc, first_item, num_items, with_long, d_x, d_state, s);
+        default:    return launch_expand_as<32768, 1024>(plan, sc, first_item, num_items, with_long, d_x, d_state, s);   // 128 KiB of LDS: one workgroup per CU
     }
 }
 
-LongSeeds long_seeds(const TiledPlan& plan) {
-    return LongSeeds{plan.long_rows, plan.long_first, plan.num_long > 0 ? plan.tile_long : nullptr, plan.long_sums};
+LongSeeds long_seeds(const TiledPlan& plan, const Scratch& sc) {
+    return LongSeeds{plan.long_rows, plan.long_first, plan.num_long > 0 ? plan.tile_long : nullptr, sc.long_sums};
 }
 
 template <int BLOCK, int E, int kRuns>
-hipError_t launch_reduce_as(const TiledPlan& plan, float* d_y, hipStream_t s) {
+hipError_t launch_reduce_as(const TiledPlan& plan, const Scratch& sc, float* d_y, hipStream_t s) {
     const size_t lds = static_cast<size_t>(plan.tile_rows) * sizeof(double);
     const void* kernel = reinterpret_cast<const void*>(&tiled_reduce_kernel<BLOCK, E, kRuns>);
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
     tiled_reduce_kernel<BLOCK, E, kRuns><<<xcd_grid(plan.num_tiles), BLOCK, lds, s>>>(
-        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_drow,
-        long_seeds(plan), plan.num_rows, d_y);
+        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, sc.prod, plan.a_drow,
+        long_seeds(plan, sc), plan.num_rows, d_y);
     return hipGetLastError();
 }
 
-hipError_t launch_reduce(const TiledPlan& plan, float* d_y, hipStream_t s) {
+hipError_t launch_reduce(const TiledPlan& plan, const Scratch& sc, float* d_y, hipStream_t s) {
     switch (plan.lane_entries) {
-        case 2:  return launch_reduce_as<1024, 2, 4>(plan, d_y, s);
-        case 4:  return launch_reduce_as<1024, 4, 2>(plan, d_y, s);
-        default: return launch_reduce_as<1024, 8, 1>(plan, d_y, s);
+        case 2:  return launch_reduce_as<1024, 2, 4>(plan, sc, d_y, s);
+        case 4:  return launch_reduce_as<1024, 4, 2>(plan, sc, d_y, s);
+        default: return launch_reduce_as<1024, 8, 1>(plan, sc, d_y, s);
     }
 }
 
 template <int BLOCK, int E, int kRuns>
-hipError_t launch_pagerank_reduce_as(const TiledPlan& plan, const RowMap& map, int n_global, const float* d_r_old,
+hipError_t launch_pagerank_reduce_as(const TiledPlan& plan, const Scratch& sc, const RowMap& map, int n_global, const float* d_r_old,
                                      float* d_r_new, const unsigned char* d_dangling, float damping,
                                      const PrState* d_state, double* d_block_partials,
                                      const PushTargets& push, hipStream_t s) {
@@ -1282,18 +1319,18 @@ hipError_t launch_pagerank_reduce_as(const TiledPlan& plan, const RowMap& map, i
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
     tiled_pagerank_reduce_kernel<BLOCK, E, kRuns><<<xcd_grid(plan.num_tiles), BLOCK, lds, s>>>(
-        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, plan.prod, plan.a_drow,
-        long_seeds(plan), plan.num_rows, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
+        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, sc.prod, plan.a_drow,
+        long_seeds(plan, sc), plan.num_rows, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
         d_block_partials, push);
     return hipGetLastError();
 }
 
-hipError_t launch_pagerank_reduce(const TiledPlan& plan, const RowMap& map, int n_global, const float* d_r_old,
+hipError_t launch_pagerank_reduce(const TiledPlan& plan, const Scratch& sc, const RowMap& map, int n_global, const float* d_r_old,
                                   float* d_r_new, const unsigned char* d_dangling, float damping,
                                   const PrState* d_state, double* d_block_partials,
                                   const PushTargets& push, hipStream_t s) {
 #define SPMV_PR_REDUCE(BLOCK, E, RUNS) \
-    launch_pagerank_reduce_as<BLOCK, E, RUNS>(plan, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state, \
+    launch_pagerank_reduce_as<BLOCK, E, RUNS>(plan, sc, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state, \
                                               d_block_partials, push, s)
     switch (plan.lane_entries) {
         case 2:  return SPMV_PR_REDUCE(1024, 2, 4);
@@ -1380,6 +1417,10 @@ void tiled_free(TiledPlan* p) {
     void* owned[] = {p->a_val, p->a_lcol, p->a_drow, p->prod, p->cells_t, p->items, p->long_rows, p->long_chunks,
                      p->long_first, p->long_sums, p->tile_long, p->col_weight};
     for (void* q : owned) if (q) (void)hipFree(q);
+    for (const TiledPlan::StreamScratch& e : p->extra_scratch) {
+        if (e.prod) (void)hipFree(e.prod);
+        if (e.long_sums) (void)hipFree(e.long_sums);
+    }
     delete[] p->strip_first_item;
     delete p;
 }
@@ -1735,19 +1776,27 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
 } // namespace
 
 hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipStream_t s) {
-    const hipError_t e = launch_expand(plan, 0, plan.num_items, true, d_x, nullptr, s);       // phase 1 + the long rows
+    Scratch sc;
+    hipError_t e = scratch_for(plan, s, &sc);
     if (e != hipSuccess) return e;
-    return launch_reduce(plan, d_y, s);
+    // two host threads may call on the same stream: the pair of launches must not interleave with another pair
+    std::lock_guard<std::mutex> pair(plan.launch_lock);
+    e = launch_expand(plan, sc, 0, plan.num_items, true, d_x, nullptr, s);       // phase 1 + the long rows
+    if (e != hipSuccess) return e;
+    return launch_reduce(plan, sc, d_y, s);
 }
 
 // After convergence the kernels of both parts return at once: r_new and the product stream stay as the last
 // committed step left them.
 hipError_t tiled_pagerank_expand(const TiledPlan& plan, int strip_begin, int strip_end, bool with_long,
                                  const float* d_r_old, const PrState* d_state, hipStream_t s) {
+    Scratch sc;
+    const hipError_t e = scratch_for(plan, s, &sc);
+    if (e != hipSuccess) return e;
     strip_begin = std::max(0, std::min(strip_begin, plan.num_strips));
     strip_end = std::max(strip_begin, std::min(strip_end, plan.num_strips));
     const int first = plan.strip_first_item[strip_begin];
-    return launch_expand(plan, first, plan.strip_first_item[strip_end] - first, with_long, d_r_old, d_state, s);
+    return launch_expand(plan, sc, first, plan.strip_first_item[strip_end] - first, with_long, d_r_old, d_state, s);
 }
 
 hipError_t tiled_pagerank_finish(const TiledPlan& plan, const RowMap& map, int n_global,
@@ -1755,7 +1804,10 @@ hipError_t tiled_pagerank_finish(const TiledPlan& plan, const RowMap& map, int n
                                  const unsigned char* d_dangling, float damping,
                                  const PrState* d_state, double* d_block_partials,
                                  const PushTargets& push, hipStream_t s) {
-    return launch_pagerank_reduce(plan, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
+    Scratch sc;
+    const hipError_t e = scratch_for(plan, s, &sc);
+    if (e != hipSuccess) return e;
+    return launch_pagerank_reduce(plan, sc, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
                                   d_block_partials, push, s);
 }
 

@@ -62,9 +62,11 @@ inline bool spmv_validate_dimensions(int num_cols, int vec_size) {
 
 // Enqueue-only variant: validates, launches on `stream`, does not time or
 // synchronise.  Returns an SpMVError as int.  Safe inside hipGraph capture.
-// A matrix's auxiliary data (merge tables, the LDS-tiled plan with its product stream) is scratch
-// shared by all calls on that matrix: calls on the SAME matrix must be ordered (one stream, or
-// events between streams); calls on different matrices may overlap freely.
+// Calls on one matrix from different streams may run at once, as with the reference's stateless kernels: what
+// a call writes next to the matrix (the tiled plan's product stream, merge-path's carry-out slots) exists once
+// per stream, allocated at a stream's first call on that matrix (also inside a graph capture); beyond eight
+// streams per matrix the tiled engine steps aside for the direct kernels.  The first call that BUILDS a
+// matrix's auxiliary data allocates and synchronises its stream — do that one outside a capture.
 int spmv_csr_async(const CSRMatrix* A, const float* d_x, float* d_y,
                    const SpMVConfig* config, int vec_size, hipStream_t stream);
 int spmv_ell_async(const ELLMatrix* A, const float* d_x, float* d_y,

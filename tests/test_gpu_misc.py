@@ -134,6 +134,40 @@ def test_async_entry_point_on_a_stream(gpu, oracle):
     gpu.csr_destroy(A)
 
 
+def test_concurrent_streams_on_one_matrix_do_not_share_scratch(gpu, oracle):
+    """The reference's kernels are stateless, so its callers may run SpMVs on ONE matrix from several streams
+    at once.  Here the tiled engine (product stream, long-row sums) and merge-path (carry-out slots) write
+    per-matrix scratch — one set per stream.  Four streams, four different x, many rounds in flight together:
+    every y must be its own product (with shared scratch the kernels of different streams overwrite each
+    other's products)."""
+    torch = pytest.importorskip("torch")
+    rows, cols = 300_000, 400_000
+    lens = gpu.synth.power_law_lengths(5, rows, max_len=30000, n_cols=cols)      # long rows: the chunk sums are scratch too
+    rp, ci, va = gpu.synth.stratified_csr(5, 0, lens, cols)
+    A = gpu.csr_from_arrays(rows, cols, rp, ci, va)
+    assert gpu.csr_to_gpu(A) == 0
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    xs = [gpu.synth.vector(5, 10 + i, cols) * np.float32(1 + i) for i in range(4)]
+    wants = [oracle.spmv_csr(rp, ci, va, x) for x in xs]
+    txs = [torch.from_numpy(x).cuda() for x in xs]
+    for cfg in (gpu.SpMVConfig(kernel_type=1, use_texture=True),        # tiled engine
+                gpu.SpMVConfig(kernel_type=2, use_texture=False)):      # merge-path on the CSR arrays
+        tys = [torch.zeros(rows, device="cuda") for _ in range(4)]
+        # first call (builds the plan / the tile table) on stream 0, then everybody at once
+        assert gpu.spmv_csr_async(A, txs[0].data_ptr(), tys[0].data_ptr(), cfg, cols, streams[0].cuda_stream) == 0
+        torch.cuda.synchronize()
+        for _ in range(12):
+            for i, st in enumerate(streams):
+                assert gpu.spmv_csr_async(A, txs[i].data_ptr(), tys[i].data_ptr(), cfg, cols, st.cuda_stream) == 0
+        torch.cuda.synchronize()
+        if cfg.use_texture:
+            assert gpu.csr_has_tiled_plan(A) and gpu.csr_tiled_info(A)["long_rows"] > 0
+        for i in range(4):
+            got = tys[i].cpu().numpy()
+            assert reorder_err(rp, ci, va, xs[i], wants[i], got) <= 1e-5, (cfg.kernel_type, i)
+    gpu.csr_destroy(A)
+
+
 def test_ell_from_csr_on_the_device_matches_the_host_conversion(gpu, oracle):
     """device-side ell_from_csr equals the reference's host conversion
     (src/ell_matrix.cpp:111-159) slab for slab, and feeds spmv_ell directly."""

@@ -101,6 +101,8 @@ class Layout:
             assert align >= 2 and align % 2 == 0
             per_chunk = (shard_len + tail + self.chunks - 1) // self.chunks
             self.piece = (per_chunk + align - 1) // align * align
+            while self.piece < TAIL:            # (tiny shards, many blocks) the tail must fit inside the last piece
+                self.piece += align
         self.block = self.piece * world
         self.padded = self.block * self.chunks
         self.shard_len = self.piece * self.chunks - tail     # rows a rank's pieces can hold

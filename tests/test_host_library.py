@@ -341,3 +341,47 @@ def test_native_multi_gpu_shard_bounds_on_the_host(spmv):
     assert lib.spmv_c_pagerank_shard_bounds(rp.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 6, 2,
                                             bounds.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))) == 0
     assert bounds.tolist() == [0, 4, 6]
+
+
+def test_shard_bounds_and_layouts_agree_on_random_inputs(spmv):
+    """Property test (hypothesis): the two loops cut a graph the same way — the C++ `pagerank_shard_bounds`
+    (native multi-GPU loop) and `Layout.equal_nnz_bounds` (one process per GPU) — and every layout the Python
+    loop can build (any world, any block count, any alignment, with or without forced exchange) numbers the
+    nodes injectively inside the vector, keeps the tails clear of them, and agrees with the engine's RowMap."""
+    import ctypes
+    import importlib
+    hyp = pytest.importorskip("hypothesis")
+    st = importlib.import_module("hypothesis.strategies")
+    prd = importlib.import_module("gpu-spmv_amd.pagerank_dist")
+    lib = spmv.lib()
+
+    @hyp.settings(max_examples=150, deadline=None)
+    @hyp.given(lens=st.lists(st.integers(0, 50), min_size=1, max_size=200), world=st.integers(1, 9),
+               chunks=st.integers(1, 5), align=st.sampled_from([None, 2, 4, 64]), forced=st.booleans())
+    def check(lens, world, chunks, align, forced):
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        n = len(lens)
+        native = np.zeros(world + 1, dtype=np.int32)
+        assert lib.spmv_c_pagerank_shard_bounds(rp.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), n, world,
+                                                native.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))) == 0
+        bounds = prd.Layout.equal_nnz_bounds(rp, world)
+        assert bounds.tolist() == native.tolist()
+        exchange = True if (forced and world == 1) else None
+        lays = [prd.Layout(n, world, r, bounds=bounds, chunks=chunks, align=align, exchange=exchange) for r in range(world)]
+        lay = lays[0]
+        pos = lay.positions()
+        assert len(set(pos.tolist())) == n and (n == 0 or (0 <= pos.min() and pos.max() < lay.padded))
+        np.testing.assert_array_equal(lay.remap_columns(np.arange(n, dtype=np.int32)), pos)
+        taken = set(pos.tolist())
+        for r, lr in enumerate(lays):
+            mine = lr.local_positions()
+            np.testing.assert_array_equal(mine, pos[lr.row_begin:lr.row_end])
+            base, piece, block = lr.row_map()
+            i = np.arange(lr.local_rows)
+            np.testing.assert_array_equal(mine, base + i if piece == 0x7FFFFFFF else base + (i // piece) * block + i % piece)
+            if lr.exchange:
+                t = lr.tail_slice()
+                assert t.start % 2 == 0 and t.stop <= lr.padded and not (set(range(t.start, t.stop)) & taken)
+                assert lr.block_slice(lr.chunks - 1).start <= t.start and t.stop == lr.piece_slice(lr.chunks - 1).stop
+
+    check()

@@ -145,6 +145,35 @@ static void containers_and_cpu_spmv(const std::string& dir) {
                     ell_destroy(victim);
                 }
             }
+            // fuzz: a few random bytes changed.  Either the loader refuses the file, or what it hands out is
+            // a matrix every later loop can index blindly — proven by running the CPU SpMV on it under ASan.
+            {
+                std::mt19937 fuzz(1234u + static_cast<unsigned>(bytes.size()));
+                for (int round = 0; round < 400 && !bytes.empty(); ++round) {
+                    std::vector<unsigned char> mutated = bytes;
+                    const int flips = 1 + static_cast<int>(fuzz() % 4);
+                    for (int k = 0; k < flips; ++k) mutated[fuzz() % mutated.size()] = static_cast<unsigned char>(fuzz());
+                    std::FILE* out = std::fopen(cut_file.c_str(), "wb");
+                    std::fwrite(mutated.data(), 1, mutated.size(), out);
+                    std::fclose(out);
+                    if (file == csr_file) {
+                        CSRMatrix* victim = csr_create(0, 0, 0);
+                        if (csr_deserialize(victim, cut_file.c_str()) == 0 && victim->num_cols <= (1 << 13) && victim->num_rows <= (1 << 13)) {   // (huge but empty is a valid matrix)
+                            std::vector<float> vx(static_cast<size_t>(victim->num_cols) + 1, 1.0f), vy(static_cast<size_t>(victim->num_rows) + 1);
+                            spmv_cpu_csr(victim, vx.data(), vy.data());
+                            (void)csr_compute_stats(victim);
+                        }
+                        csr_destroy(victim);
+                    } else {
+                        ELLMatrix* victim = ell_create(0, 0, 0);
+                        if (ell_deserialize(victim, cut_file.c_str()) == 0 && victim->num_cols <= (1 << 13) && victim->num_rows <= (1 << 13)) {
+                            std::vector<float> vx(static_cast<size_t>(victim->num_cols) + 1, 1.0f), vy(static_cast<size_t>(victim->num_rows) + 1);
+                            spmv_cpu_ell(victim, vx.data(), vy.data());
+                        }
+                        ell_destroy(victim);
+                    }
+                }
+            }
             // arrays that do not describe a matrix: a column index out of range, a row pointer running backwards
             if (file == csr_file && csr->nnz > 0 && rows > 1) {
                 const size_t col0 = 12 + 4 * static_cast<size_t>(csr->nnz), ptr1 = 12 + 8 * static_cast<size_t>(csr->nnz) + 4;

@@ -282,6 +282,32 @@ def test_tiled_engine_power_law_empty_rows_and_unaligned_x(gpu, oracle):
     assert (got[lens == 0] == 0).all()
 
 
+def test_tiled_engine_keeps_nan_and_inf_where_they_belong(gpu, oracle):
+    """A NaN and an Inf in x reach exactly the rows that have an entry in those columns — the skip markers and the
+    padding slots of the bucketed layout multiply 0 by x[first column of the strip] and must not carry the result
+    into any row (here: the poisoned columns ARE strip starts)."""
+    rows, cols = 200_000, 300_000
+    rp, ci, va = gpu.synth.uniform_csr(9, 0, rows, cols, 6)
+    x = gpu.synth.vector(9, 2, cols)
+    x[0] = np.nan                 # column 0 = first column of strip 0: what every marker of that strip reads
+    x[16384] = np.inf             # (a strip start for 4096-, 8192- and 16384-column strips)
+    x[8192] = -np.inf
+    want = oracle.spmv_csr(rp, ci, va, x)
+    touched = np.zeros(rows, dtype=bool)
+    row_of = np.repeat(np.arange(rows), np.diff(rp))
+    touched[row_of[np.isin(ci, [0, 8192, 16384])]] = True
+    assert 0 < touched.sum() < 100
+    for kernel in (1, 2):
+        got = run_tiled(gpu, rp, ci, va, cols, x, kernel)
+        assert np.isfinite(got[~touched]).all()
+        clean = ~touched
+        # (6 entries per row, |a|, |x| < 1: the reordering bound 1e-5 * sum |a x| is at most 6e-5)
+        np.testing.assert_allclose(got[clean], want[clean], rtol=1e-5, atol=6e-5)
+        np.testing.assert_array_equal(np.isnan(got[touched]), np.isnan(want[touched]))
+        both_inf = np.isinf(want[touched])
+        np.testing.assert_array_equal(got[touched][both_inf], want[touched][both_inf])
+
+
 def test_tiled_engine_nonnegative_relative_error(gpu, oracle):
     rp, ci, va = gpu.synth.uniform_csr(3, 0, 200_000, 500_000, 16)
     va = np.abs(va) + np.float32(0.01)

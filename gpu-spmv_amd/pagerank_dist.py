@@ -290,8 +290,8 @@ class HipEngine:
     def commit_gathered(self, gathered: torch.Tensor, tolerance: float) -> None:
         """`gathered`: the whole vector; the ranks' partial sums sit in the tails of its last block."""
         lay = self.layout
-        last = gathered[lay.block_slice(lay.chunks - 1)]
-        self._check(lib().spmv_c_pr_commit_gathered(self._shard, c_void_p(last.data_ptr()), lay.world,
+        last = gathered.data_ptr() + 4 * lay.block_slice(lay.chunks - 1).start      # (no tensor view: this runs every step)
+        self._check(lib().spmv_c_pr_commit_gathered(self._shard, c_void_p(last), lay.world,
                                                     lay.piece, lay.piece - TAIL, tolerance, self._stream()),
                     "pr_commit_gathered")
 
@@ -344,6 +344,7 @@ class ShardedPageRank:
         self.mode = "gather"
         self._peer_ptrs = None
         self._peer_keepalive = []
+        self._view_cache = {}
         # overlapped exchange: the collectives are issued from a side stream so that the compute stream is
         # free to multiply block c while block c + 1 is still on the links
         self._comm = torch.cuda.Stream(self.device) if self.device.type == "cuda" and layout.chunks > 1 else None
@@ -383,15 +384,29 @@ class ShardedPageRank:
             dist.barrier(group=self.group)      # nobody frees a vector a peer still has mapped
         del had_peers
         self.r = []
+        self._view_cache = {}
         for ptr in self._owned:
             lib().spmv_c_device_free(ptr)
         self._owned = []
 
+    # The views an iteration needs are made once per rank vector (a slice + view costs a few microseconds each,
+    # and at eight ranks the whole step is ~200 us).
+    def _views(self, buf):
+        key = buf.data_ptr()
+        cached = self._view_cache.get(key)
+        if cached is None:
+            lay = self.layout
+            cached = {"tail": buf[lay.tail_slice()].view(torch.float64) if lay.exchange else None,
+                      "pieces": [buf[lay.piece_slice(c)] for c in range(lay.chunks)],
+                      "blocks": [buf[lay.block_slice(c)] for c in range(lay.chunks)]}
+            self._view_cache[key] = cached
+        return cached
+
     def _my_slice(self, buf, c=0):
-        return buf[self.layout.piece_slice(c)]
+        return self._views(buf)["pieces"][c]
 
     def _my_tail(self, buf):
-        return buf[self.layout.tail_slice()].view(torch.float64)
+        return self._views(buf)["tail"]
 
     # -- one-time setup: dangling mask from the globally summed column sums ------------
     def prepare(self):
@@ -508,17 +523,18 @@ class ShardedPageRank:
         # overlapped: one all-gather per block, issued back to back; as each completes, the next step's
         # products for the columns of that block are computed (the engine skips them when the step comes)
         works = []
+        views = self._views(r_new)
         if self._comm is not None:
             stepped = torch.cuda.Event()
             stepped.record()
             self._comm.wait_event(stepped)
             with torch.cuda.stream(self._comm):
                 for c in range(lay.chunks):
-                    works.append(dist.all_gather_into_tensor(r_new[lay.block_slice(c)], self._my_slice(r_new, c),
+                    works.append(dist.all_gather_into_tensor(views["blocks"][c], views["pieces"][c],
                                                              group=self.group, async_op=True))
         else:
             for c in range(lay.chunks):
-                works.append(dist.all_gather_into_tensor(r_new[lay.block_slice(c)], self._my_slice(r_new, c),
+                works.append(dist.all_gather_into_tensor(views["blocks"][c], views["pieces"][c],
                                                          group=self.group, async_op=True))
         for c, work in enumerate(works):
             work.wait()                         # the compute stream waits for block c (no host block on a GPU)

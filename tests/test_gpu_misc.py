@@ -289,3 +289,41 @@ def test_host_threads_on_their_own_matrices(gpu, oracle):
     for t in threads:
         t.join(timeout=300)
     assert not failures, failures
+
+
+def test_host_threads_sharing_one_matrix(gpu, oracle):
+    """Four host threads on ONE matrix and the same (default) stream, each with its own x and y, racing to the
+    first call (plan / tile-table build) and then calling spmv_csr in a loop through the tiled engine, merge-path
+    and vector-CSR: the two launches of a call must stay together and the builds must happen once."""
+    import threading
+    rows, cols = 200_000, 300_000
+    lens = gpu.synth.power_law_lengths(8, rows, max_len=20000, n_cols=cols)
+    rp, ci, va = gpu.synth.stratified_csr(8, 0, lens, cols)
+    A = gpu.csr_from_arrays(rows, cols, rp, ci, va)
+    assert gpu.csr_to_gpu(A) == 0
+    xs = [gpu.synth.vector(8, 20 + i, cols) * np.float32(1 + i) for i in range(4)]
+    wants = [oracle.spmv_csr(rp, ci, va, x) for x in xs]
+    failures = []
+    gate = threading.Barrier(4)
+
+    def worker(index):
+        try:
+            d_x, d_y = gpu.CudaBuffer(cols), gpu.CudaBuffer(rows)
+            d_x.copyFromHost(xs[index], cols)
+            gate.wait(timeout=60)
+            for call in range(15):
+                kind = call % 3
+                cfg = gpu.SpMVConfig(kernel_type=(1, 2, 2)[kind], use_texture=kind != 2)      # tiled, tiled, direct merge-path
+                assert gpu.spmv_csr(A, d_x, d_y, cfg, cols).error_code == 0
+                assert reorder_err(rp, ci, va, xs[index], wants[index], d_y.copyToHost(rows)) <= 1e-5, (index, call)
+        except Exception as exc:            # noqa: BLE001 - reported by the main thread
+            failures.append((index, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not failures, failures
+    assert gpu.csr_has_tiled_plan(A)
+    gpu.csr_destroy(A)

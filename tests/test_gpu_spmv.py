@@ -598,11 +598,13 @@ def _csr_from_lengths_and_cols(lens, col_fn, rng):
     return rp.astype(np.int32), ci, va
 
 
-@pytest.mark.parametrize("shape", ["banded", "one_strip", "few_long_rows", "duplicate_columns", "dense_column"])
+@pytest.mark.parametrize("shape", ["banded", "one_strip", "few_long_rows", "duplicate_columns", "dense_column",
+                                   "unsorted_columns", "explicit_zeros"])
 def test_tiled_engine_adversarial_structure(gpu, oracle, shape):
     """Structures that stress the cells of the tiled engine: every entry of a row in one strip
     (banded), every entry of the matrix in one strip, rows far longer than the long-row limit,
-    repeated (row, column) pairs, one column referenced by every row."""
+    repeated (row, column) pairs, one column referenced by every row, rows whose columns are stored in descending
+    order (legal CSR; the reference never sorts), stored zeros (values and a whole column of them)."""
     rng = np.random.default_rng(17)
     if shape == "banded":
         rows = cols = 300_000
@@ -621,6 +623,16 @@ def test_tiled_engine_adversarial_structure(gpu, oracle, shape):
         rows, cols = 200_000, 150_000
         lens = np.full(rows, 10)
         rp, ci, va = _csr_from_lengths_and_cols(lens, lambda r, s: (r * 3 + (s // 2) * 50_021) % cols, rng)
+    elif shape == "unsorted_columns":
+        rows, cols = 250_000, 400_000
+        lens = np.full(rows, 12)
+        rp, ci, va = _csr_from_lengths_and_cols(lens, lambda r, s: (r * 11 + (11 - s) * 30_011) % cols, rng)
+    elif shape == "explicit_zeros":
+        rows, cols = 250_000, 400_000
+        lens = np.full(rows, 8)
+        rp, ci, va = _csr_from_lengths_and_cols(lens, lambda r, s: np.where(s == 3, 123_456, (r * 13 + s * 40_009) % cols), rng)
+        va[::3] = 0.0
+        va[ci == 123_456] = 0.0                       # a column that holds nothing but stored zeros
     else:
         rows, cols = 500_000, 100_000
         lens = np.full(rows, 4)

@@ -291,7 +291,7 @@ def main():
                    "plan_build_ms": plan_info.get("build_ms") if plan_info else None,
                    "plan_bytes": plan_info.get("plan_bytes") if plan_info else None,
                    "plan_note": "one-time per matrix, outside the timed region; break-even against the direct kernel "
-                                "after ~4 SpMVs (pagerank() starts on the direct kernel and builds it after 4 steps)",
+                                "after ~3 SpMVs (pagerank() starts on the direct kernel and builds it after 4 steps)",
                    "parallelism": "row-shard x%d%s" % (world, "" if world == 1 else
                        " + %d RCCL all-gather(s) per step (%d f32/rank each, partial sums in the slice tails)"
                        % (layout.chunks, layout.piece)),

@@ -187,6 +187,7 @@ _SIGNATURES = {
     "spmv_c_tiled_shape": (c_int, [c_int64, c_int64, c_int64, POINTER(c_int32), POINTER(c_int32)]),
     "spmv_c_csr_tiled_info": (c_int, [POINTER(CSRMatrix), POINTER(c_int64)]),
     "spmv_c_csr_tiled_stats": (c_int, [POINTER(CSRMatrix), POINTER(c_double)]),
+    "spmv_c_csr_tiled_checksum": (c_int, [POINTER(CSRMatrix), POINTER(c_uint64)]),
     "spmv_c_csr_tiled_folded": (c_int, [POINTER(CSRMatrix)]),
     "spmv_c_spmv_csr_async": (c_int, [POINTER(CSRMatrix), c_void_p, c_void_p, POINTER(SpMVConfig), c_int,
                                       c_void_p]),
@@ -600,6 +601,15 @@ def spmv_ell(A, d_x, d_y, config=None, vec_size=-1) -> SpMVResult:
     lib().spmv_c_spmv_ell(A, _dev(d_x), _dev(d_y), byref(config) if config is not None else None,
                           vec_size, byref(out))
     return out
+
+
+def csr_tiled_checksum(A):
+    """Four position-weighted checksums of the matrix's tiled plan (values, local columns, row deltas, cell
+    table), or None without a plan."""
+    out = (c_uint64 * 4)()
+    if not lib().spmv_c_csr_tiled_checksum(A, out):
+        return None
+    return tuple(int(v) for v in out)
 
 
 def csr_has_tiled_plan(A) -> bool:

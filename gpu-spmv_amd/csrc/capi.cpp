@@ -322,6 +322,17 @@ int spmv_c_csr_tiled_stats(const spmv_c_csr* A_c, double out[4]) {
     return 1;
 }
 
+int spmv_c_csr_tiled_checksum(const spmv_c_csr* A_c, uint64_t out[4]) {
+    const CSRMatrix* A = cxx(A_c);
+    if (!A || !A->d_row_ptrs || !out) return 0;
+    const detail::PlanRef plan = detail::tiled_plan_if_cached(A);
+    if (!plan) return 0;
+    unsigned long long sums[4] = {0, 0, 0, 0};
+    if (detail::tiled_checksum(*plan, sums, detail::current_stream()) != hipSuccess) return 0;
+    for (int i = 0; i < 4; ++i) out[i] = sums[i];
+    return 1;
+}
+
 int spmv_c_csr_tiled_folded(const spmv_c_csr* A_c) {
     const CSRMatrix* A = cxx(A_c);
     if (!A || !A->d_row_ptrs) return 0;

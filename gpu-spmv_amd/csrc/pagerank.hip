@@ -620,7 +620,9 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     // (the 10 M-node uniform graph: 3 iterations).  So: a plan the matrix already holds is used from the
     // first step; otherwise the loop starts on the direct kernel and builds the plan only once it has
     // spent about one build's worth of time on direct steps (ski rental: never more than ~2x the better
-    // choice).  Estimates per stored entry, measured on C5: build 50 ps, direct step 17 ps, tiled step 3.3 ps.
+    // choice).  Estimates per stored entry, measured on C5: build 34 ps, direct step 17 ps, tiled step 3.3 ps:
+    // break-even after 2.5 direct steps.  One more than that: the loop enqueues one step past convergence, and
+    // that step of a run that converges in exactly three (the 10 M-node uniform graph) should not start a build.
     // The matrix's workspace goes to one call at a time; a second call running concurrently on the same matrix
     // gets a private one — and stays on the direct kernels, because a step through the tiled engine is two
     // launches around the plan's product stream and two loops interleaving on one stream would mix them up.
@@ -628,7 +630,7 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     detail::PlanRef plan = ws.is_private() ? detail::PlanRef() : detail::tiled_plan_if_cached(adj);
     int build_plan_at = -1;
     if (!plan && !ws.is_private() && detail::tiled_eligible(adj)) {
-        build_plan_at = static_cast<int>(std::ceil(50.0 / (17.0 - 3.3)));            // = 4 direct steps
+        build_plan_at = static_cast<int>(std::ceil(34.0 / (17.0 - 3.3))) + 1;        // = 4 direct steps
         if (const char* env = std::getenv("SPMV_PR_PLAN_AFTER")) build_plan_at = std::max(0, std::atoi(env));
         if (build_plan_at == 0) plan = detail::tiled_plan_for(adj, stream);
     }

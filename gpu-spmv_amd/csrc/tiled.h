@@ -89,6 +89,9 @@ hipError_t tiled_build(const CSRMatrix* A, TiledPlan** out, hipStream_t s);
 hipError_t tiled_build(const ELLMatrix* A, TiledPlan** out, hipStream_t s);   // from the ELL slabs (no long-row path)
 void tiled_free(TiledPlan* plan);
 
+// position-weighted checksums of a_val / a_lcol / a_drow / cells_t (test aid: equal plans, equal numbers)
+hipError_t tiled_checksum(const TiledPlan& plan, unsigned long long out[4], hipStream_t s);
+
 // y = A x.  hipErrorOutOfMemory: no scratch for this (additional) stream — the caller may use another kernel.
 hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipStream_t s);
 

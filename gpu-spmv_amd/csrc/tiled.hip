@@ -57,6 +57,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace spmv {
@@ -505,10 +506,12 @@ void batch_place_kernel(Src src, BuildShape sh, int num_batches,
                         const uint2* __restrict__ groups,              // [batches * strips] GroupPlace
                         const unsigned int* __restrict__ meta, const int* __restrict__ offs,
                         float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
-                        unsigned char* __restrict__ a_drow) {
+                        unsigned char* __restrict__ a_drow,
+                        const unsigned char* __restrict__ todo /*null: every batch; else only the flagged ones*/) {
     extern __shared__ int place_lds[];
     const int batch = xcd_contiguous(blockIdx.x, num_batches);
     if (batch < 0) return;
+    if (todo && !todo[batch]) return;
     const int S = sh.num_strips;
     uint2* place = reinterpret_cast<uint2*>(place_lds);
     int* cell_begin = place_lds + 2 * S;
@@ -562,6 +565,147 @@ void batch_place_kernel(Src src, BuildShape sh, int num_batches,
             a_lcol[at + need] = static_cast<unsigned short>(c[u] - (strip << sh.strip_shift));
             a_drow[at + need] = static_cast<unsigned char>(delta);
         }
+    }
+}
+
+// The same placing pass with the batch's slots assembled in LDS first, in destination order, so that the global
+// stores leave the workgroup as contiguous segments (one per group and array) instead of one element per lane:
+// the scattered form above issues ~3 partial-line writes per entry (C5: 480 M of them, 3.8 ms), this one ~3 per
+// GROUP.  Takes the batches whose entries a workgroup can hold in registers (entry range <= capacity) and whose
+// slots (markers included) fit the staging area; every other batch is left to batch_place_kernel (`todo` flag).
+// Dynamic LDS: per strip place (8 B), cell begin, slot count, local offset (4 B each); per staged slot value f32,
+// local column u16, strip u16, row delta u8.
+constexpr int kStageBytesPerStrip = 20, kStageBytesPerSlot = 9;
+template <typename Src>
+__global__ __launch_bounds__(kBuildBlock, 8)
+void batch_place_staged_kernel(Src src, BuildShape sh, int num_batches, int capacity, int stage_slots,
+                               const int* __restrict__ batch_row, const int* __restrict__ batch_tile,
+                               const uint2* __restrict__ groups,              // [batches * strips] GroupPlace
+                               const unsigned int* __restrict__ meta, const int* __restrict__ offs,
+                               float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
+                               unsigned char* __restrict__ a_drow, unsigned char* __restrict__ todo) {
+    extern __shared__ int stage_lds[];
+    __shared__ int s_partial[kBuildBlock];
+    const int batch = xcd_contiguous(blockIdx.x, num_batches);
+    if (batch < 0) return;
+    const int S = sh.num_strips;
+    uint2* place = reinterpret_cast<uint2*>(stage_lds);                 // [S]
+    int* cell_begin = stage_lds + 2 * S;                                 // [S]
+    int* count = stage_lds + 3 * S;                                      // [S] slots of the batch per strip
+    int* local = stage_lds + 4 * S;                                      // [S] first staged slot of the strip
+    float* st_val = reinterpret_cast<float*>(stage_lds + 5 * S);         // [stage_slots]
+    unsigned short* st_lcol = reinterpret_cast<unsigned short*>(st_val + stage_slots);
+    unsigned short* st_strip = st_lcol + stage_slots;
+    unsigned char* st_drow = reinterpret_cast<unsigned char*>(st_strip + stage_slots);
+
+    const int tile = batch_tile[batch];
+    const int row0 = batch_row[batch];
+    const long long tile_end = min(static_cast<long long>(tile + 1) * sh.tile_rows, static_cast<long long>(sh.num_rows));
+    const int row1 = batch + 1 < num_batches && batch_tile[batch + 1] == tile ? batch_row[batch + 1]
+                                                                                : static_cast<int>(tile_end);
+    const long long entry0 = src.offset(row0), entry1 = src.offset(row1);
+    if (entry1 - entry0 > capacity) {          // (a batch with long rows inside: the scattered kernel takes it)
+        if (threadIdx.x == 0) todo[batch] = 1;
+        return;
+    }
+    const int span = static_cast<int>(entry1 - entry0);
+    for (int i = threadIdx.x; i < S; i += kBuildBlock) {
+        place[i] = groups[static_cast<long long>(batch) * S + i];
+        cell_begin[i] = offs[static_cast<long long>(i) * sh.num_tiles + tile];
+        count[i] = 0;
+    }
+    __syncthreads();
+
+    // every thread keeps its entries: strip, local column, slots it needs (itself + the markers in front of it),
+    // position inside its group
+    int my_strip[kBuildPerThread], my_front[kBuildPerThread], my_need[kBuildPerThread], my_delta[kBuildPerThread];
+    float my_val[kBuildPerThread];
+    unsigned short my_lcol[kBuildPerThread];
+#pragma unroll
+    for (int u = 0; u < kBuildPerThread; ++u) {
+        const int idx = threadIdx.x + u * kBuildBlock;
+        my_strip[u] = -1;
+        if (idx < span) {
+            const long long j = entry0 + idx;
+            const int c = src.col(j);
+            const unsigned int m = meta[j];
+            if (c >= 0 && m != kMetaSkip) {
+                const int strip = c >> sh.strip_shift;
+                GroupPlace p;
+                __builtin_memcpy(&p, &place[strip], sizeof(p));
+                my_strip[u] = strip;
+                my_lcol[u] = static_cast<unsigned short>(c - (strip << sh.strip_shift));
+                my_val[u] = a_val ? src.val(j) : 0.0f;
+                if (m & kMetaFirst) {
+                    my_need[u] = p.lead;
+                    my_delta[u] = static_cast<int>(m & 0xFFFF) - p.prev_last - my_need[u] * kSkip;
+                    my_front[u] = 0;
+                } else {
+                    my_need[u] = (m >> 8) & 0xFF;
+                    my_delta[u] = m & 0xFF;
+                    my_front[u] = p.lead + static_cast<int>(m >> 16) - my_need[u];
+                }
+                atomicAdd(&count[strip], 1 + my_need[u]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // exclusive scan of the per-strip slot counts (every thread owns a contiguous piece of the strips)
+    int total;
+    {
+        const int per = (S + kBuildBlock - 1) / kBuildBlock;
+        const int lo = min(S, per * static_cast<int>(threadIdx.x)), hi = min(S, lo + per);
+        int sum = 0;
+        for (int i = lo; i < hi; ++i) sum += count[i];
+        s_partial[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = 1; off < kBuildBlock; off <<= 1) {
+            const int add = static_cast<int>(threadIdx.x) >= off ? s_partial[threadIdx.x - off] : 0;
+            __syncthreads();
+            s_partial[threadIdx.x] += add;
+            __syncthreads();
+        }
+        int run = threadIdx.x ? s_partial[threadIdx.x - 1] : 0;
+        for (int i = lo; i < hi; ++i) {
+            local[i] = run;
+            run += count[i];
+        }
+        total = s_partial[kBuildBlock - 1];
+    }
+    __syncthreads();
+    if (total > stage_slots) {                 // (markers galore: more slots than the staging area holds)
+        if (threadIdx.x == 0) todo[batch] = 1;
+        return;
+    }
+
+    // assemble the batch's slots in destination order
+#pragma unroll
+    for (int u = 0; u < kBuildPerThread; ++u) {
+        if (my_strip[u] < 0) continue;
+        const int at = local[my_strip[u]] + my_front[u];
+        for (int k = 0; k < my_need[u]; ++k) {
+            st_val[at + k] = 0.0f;
+            st_lcol[at + k] = 0;
+            st_strip[at + k] = static_cast<unsigned short>(my_strip[u]);
+            st_drow[at + k] = kSkip;
+        }
+        st_val[at + my_need[u]] = my_val[u];
+        st_lcol[at + my_need[u]] = my_lcol[u];
+        st_strip[at + my_need[u]] = static_cast<unsigned short>(my_strip[u]);
+        st_drow[at + my_need[u]] = static_cast<unsigned char>(my_delta[u]);
+    }
+    __syncthreads();
+
+    // ... and write them out: consecutive lanes, consecutive slots of a group, consecutive addresses
+    for (int u = threadIdx.x; u < total; u += kBuildBlock) {
+        const int strip = st_strip[u];
+        GroupPlace p;
+        __builtin_memcpy(&p, &place[strip], sizeof(p));
+        const long long at = static_cast<long long>(cell_begin[strip]) + p.rel + (u - local[strip]);
+        if (a_val) a_val[at] = st_val[u];
+        a_lcol[at] = st_lcol[u];
+        a_drow[at] = st_drow[u];
     }
 }
 
@@ -1440,11 +1584,12 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     long long* block_sum = nullptr;    // scan scratch; [blocks] sums, then [blocks] grand total, [blocks + 1] entry count
     uint2* groups = nullptr;
     unsigned int* meta = nullptr;      // per-entry records between the ranking and the placing pass
+    unsigned char* place_todo = nullptr;   // batches the staged placing pass left to the scattered one
     auto cleanup = [&](hipError_t e) {
         for (void* q : {static_cast<void*>(d_small), static_cast<void*>(tile_batch), static_cast<void*>(batch_row),
                         static_cast<void*>(batch_tile), static_cast<void*>(cell_slots), static_cast<void*>(offs),
                         static_cast<void*>(strip_begin), static_cast<void*>(block_sum), static_cast<void*>(groups),
-                        static_cast<void*>(meta)}) {
+                        static_cast<void*>(meta), static_cast<void*>(place_todo)}) {
             if (q) (void)hipFree(q);
         }
         return e;
@@ -1535,8 +1680,34 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     if (e == hipSuccess) e = dev_alloc(&plan->cells_t, 2 * cells);
     if (e != hipSuccess) return cleanup(e);
     if (plan->nnz > 0) {
+        // staged placing pass (contiguous segments); the batches it cannot hold are flagged for the scattered one
+        bool staged = true;
+        if (const char* env = std::getenv("SPMV_TILED_PLACE")) staged = std::strcmp(env, "scattered") != 0;
+        unsigned char* todo = nullptr;
+        if (staged) {
+            const int stage_slots = (capacity + 1024 + 63) / 64 * 64;
+            const size_t stage_lds = static_cast<size_t>(kStageBytesPerStrip) * S + static_cast<size_t>(kStageBytesPerSlot) * stage_slots;
+            staged = stage_lds + sizeof(int) * kBuildBlock + 64 <= 160 * 1024;
+            if (staged) e = dev_alloc(&todo, num_batches);
+            if (staged && e == hipSuccess) e = hipMemsetAsync(todo, 0, num_batches, s);
+            if (staged && e == hipSuccess) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_place_staged_kernel<Src>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(stage_lds));
+            }
+            if (e != hipSuccess) {
+                if (todo) (void)hipFree(todo);
+                return cleanup(e);
+            }
+            if (staged) {
+                batch_place_staged_kernel<Src><<<xcd_grid(num_batches), kBuildBlock, stage_lds, s>>>(
+                    dev_src, sh, num_batches, capacity, stage_slots, batch_row, batch_tile, groups, meta, offs,
+                    plan->a_val, plan->a_lcol, plan->a_drow, todo);
+            }
+        }
         batch_place_kernel<Src><<<xcd_grid(num_batches), kBuildBlock, 12 * static_cast<size_t>(S), s>>>(
-            dev_src, sh, num_batches, batch_row, batch_tile, groups, meta, offs, plan->a_val, plan->a_lcol, plan->a_drow);
+            dev_src, sh, num_batches, batch_row, batch_tile, groups, meta, offs, plan->a_val, plan->a_lcol, plan->a_drow,
+            staged ? todo : nullptr);
+        place_todo = todo;
         cell_padding_kernel<<<static_cast<int>(std::min<long long>((cells + kBlock - 1) / kBlock, 4096)), kBlock, 0, s>>>(
             cell_slots, offs, cells, plan->a_val, plan->a_lcol, plan->a_drow);
     }
@@ -1774,6 +1945,56 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
 }
 
 } // namespace
+
+namespace {
+// position-weighted checksums of the three slot arrays and of the cell table (a debugging / test aid: two
+// builds of one matrix must give the same four numbers whatever path the builder took)
+__global__ __launch_bounds__(kBlock)
+void plan_checksum_kernel(long long slots, const float* __restrict__ a_val, const unsigned short* __restrict__ a_lcol,
+                          const unsigned char* __restrict__ a_drow, long long table_ints, const int* __restrict__ cells_t,
+                          unsigned long long* __restrict__ out /*[4]*/) {
+    unsigned long long v = 0, c = 0, d = 0, t = 0;
+    for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < slots;
+         i += static_cast<long long>(gridDim.x) * kBlock) {
+        const unsigned long long w = 2 * static_cast<unsigned long long>(i) + 1;
+        if (a_val) v += w * __float_as_uint(a_val[i]);
+        c += w * a_lcol[i];
+        d += w * a_drow[i];
+    }
+    for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < table_ints;
+         i += static_cast<long long>(gridDim.x) * kBlock) {
+        t += (2 * static_cast<unsigned long long>(i) + 1) * static_cast<unsigned int>(cells_t[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        v += __shfl_xor(v, off, 64);
+        c += __shfl_xor(c, off, 64);
+        d += __shfl_xor(d, off, 64);
+        t += __shfl_xor(t, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], v);
+        atomicAdd(&out[1], c);
+        atomicAdd(&out[2], d);
+        atomicAdd(&out[3], t);
+    }
+}
+} // namespace
+
+hipError_t tiled_checksum(const TiledPlan& plan, unsigned long long out[4], hipStream_t s) {
+    unsigned long long* d_out = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), 4 * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d_out, 0, 4 * sizeof(unsigned long long), s);
+    if (e == hipSuccess) {
+        plan_checksum_kernel<<<1024, kBlock, 0, s>>>(plan.nnz, plan.a_val, plan.a_lcol, plan.a_drow,
+                                                     2LL * plan.num_strips * plan.num_tiles, plan.cells_t, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_out);
+    return e;
+}
 
 hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipStream_t s) {
     Scratch sc;

@@ -202,6 +202,9 @@ int spmv_c_csr_tiled_info(const spmv_c_csr* A, int64_t out[8]);
 /* extension: what the plan cost — out[4] = build time in ms (host wall clock, allocations included),
  * device bytes held, slots in cells, matrix entries in cells; returns 0 if the matrix has no plan */
 int spmv_c_csr_tiled_stats(const spmv_c_csr* A, double out[4]);
+/* position-weighted checksums of the plan's slot arrays (values, local columns, row deltas) and its cell table:
+ * two builds of one matrix give the same four numbers (the layout is a pure function of the matrix).  1 = filled. */
+int spmv_c_csr_tiled_checksum(const spmv_c_csr* A, uint64_t out[4]);
 /* extension: 1 when the matrix's plan folded its values into one weight per column (every stored
  * entry of a column bit-identical: adjacency / column-stochastic matrices), so that the tiled engine
  * streams no values; 0 otherwise or without a plan.  SPMV_TILED_FOLD=0 at build time disables it. */

@@ -357,6 +357,57 @@ def test_tiled_engine_is_reproducible_run_to_run_and_across_plan_rebuilds(gpu):
         A.close()
 
 
+def test_both_placing_passes_build_the_same_plan(gpu, monkeypatch):
+    """The builder's placing pass has two forms — slots assembled in LDS and stored as contiguous segments, or one
+    scattered store per entry (what batches with long rows inside, or with more skip markers than the staging
+    area holds, fall back to).  The layout is a pure function of the matrix, so both must produce the same bytes:
+    equal checksums of the value / column / row-delta arrays and of the cell table, and bit-equal y — on a
+    uniform matrix, a power-law one (long rows: mixed batches) and one whose rows are so far apart that almost
+    every slot needs skip markers."""
+    wl = importlib.import_module("gpu-spmv_amd.workloads")
+    sparse_rows = 9_000_000
+    lens = np.zeros(sparse_rows, dtype=np.int64)
+    lens[::300] = 40                                   # 30000 rows with entries, 300 rows apart: every row change inside a cell needs a skip marker
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+
+    def far_apart():
+        A = wl.DeviceCSR(sparse_rows, 400_000, int(rp[-1]))
+        A.row_ptrs.copyFromHost(rp.astype(np.int32), sparse_rows + 1)
+        assert gpu.lib().spmv_c_gen_stratified_rows(5, 0, sparse_rows, 400_000, A.row_ptrs.get(), A.col_indices.get(),
+                                                    A.values.get(), None) == 0
+        gpu.device_synchronize()
+        return A
+
+    for make, kernel in ((lambda: wl.uniform_csr_device(6, 500_000, 800_000, 10), 1),
+                         (lambda: wl.power_law_csr_device(6, 400_000, 600_000), 2),
+                         (far_apart, 1)):
+        A = make()
+        assert gpu.tiled_shape(A.rows, A.cols, A.nnz)[0]
+        x = wl.vector_device(6, 1, A.cols)
+        y = gpu.CudaBuffer(A.rows)
+        cfg = gpu.SpMVConfig(kernel, 256, True)
+        seen = {}
+        for form in ("staged", "scattered", "staged"):
+            monkeypatch.setenv("SPMV_TILED_PLACE", form)
+            gpu.csr_invalidate_gpu_cache(A.handle)
+            assert gpu.spmv_csr(A.handle, x, y, cfg, A.cols).error_code == 0
+            sums = gpu.csr_tiled_checksum(A.handle)
+            assert sums is not None
+            info = gpu.csr_tiled_info(A.handle)
+            if make is far_apart:
+                assert info["slots_in_cells"] > info["entries_in_cells"] * 1.2      # markers really are everywhere
+            bits = y.copyToHost(A.rows).view(np.uint32).copy()
+            if seen:
+                assert sums == seen["sums"], (form, sums, seen["sums"])
+                assert np.array_equal(bits, seen["bits"]), form
+            else:
+                seen = {"sums": sums, "bits": bits}
+        monkeypatch.delenv("SPMV_TILED_PLACE")
+        x.release()
+        y.release()
+        A.close()
+
+
 def test_tiled_engine_folds_column_uniform_values(gpu, oracle, monkeypatch):
     """Every stored entry of a column equal (a_ij = 1 / outdeg(j), adjacency matrices): the plan keeps one
     weight per column and streams no values; one differing entry, or SPMV_TILED_FOLD=0, keeps the value

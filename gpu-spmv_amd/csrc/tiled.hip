@@ -56,6 +56,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -1572,9 +1573,37 @@ void tiled_free(TiledPlan* p) {
 namespace {
 
 // the device passes of the build for one entry source
+// The build's temporaries are carved out of two allocations: every hipFree synchronises the device, and eleven
+// of them were ~0.8 ms of a 5.5 ms build.
+struct BuildArena {
+    char* base = nullptr;
+    size_t size = 0, used = 0;
+    static size_t padded(size_t bytes) { return (bytes + 255) / 256 * 256; }
+    template <typename T>
+    T* take(long long count) {
+        T* p = reinterpret_cast<T*>(base + used);
+        used += padded(static_cast<size_t>(std::max<long long>(count, 1)) * sizeof(T));
+        return p;
+    }
+};
+
+// SPMV_TRACE=1: wall-clock time of each host phase of a plan build, on stderr
+struct BuildTrace {
+    bool on = std::getenv("SPMV_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void mark(const char* phase) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[spmv trace] plan build: %-28s %8.3f ms\n", phase,
+                     std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
 template <typename Src>
 hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, bool want_values,
                        std::vector<int>* host_strip, hipStream_t s) {
+    BuildTrace trace;
     const int S = plan->num_strips, T = plan->num_tiles;
     const long long cells = static_cast<long long>(S) * T;
 
@@ -1585,11 +1614,9 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     uint2* groups = nullptr;
     unsigned int* meta = nullptr;      // per-entry records between the ranking and the placing pass
     unsigned char* place_todo = nullptr;   // batches the staged placing pass left to the scattered one
+    BuildArena first, second;     // what is known up front; what depends on the batch count
     auto cleanup = [&](hipError_t e) {
-        for (void* q : {static_cast<void*>(d_small), static_cast<void*>(tile_batch), static_cast<void*>(batch_row),
-                        static_cast<void*>(batch_tile), static_cast<void*>(cell_slots), static_cast<void*>(offs),
-                        static_cast<void*>(strip_begin), static_cast<void*>(block_sum), static_cast<void*>(groups),
-                        static_cast<void*>(meta), static_cast<void*>(place_todo)}) {
+        for (void* q : {static_cast<void*>(first.base), static_cast<void*>(second.base), static_cast<void*>(strip_begin)}) {
             if (q) (void)hipFree(q);
         }
         return e;
@@ -1597,12 +1624,19 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     const int scan_blocks = static_cast<int>((cells + kScanTile - 1) / kScanTile);
     const int tile_scan_blocks = (T + kScanTile - 1) / kScanTile;
 
-    hipError_t e = dev_alloc(&d_small, 2);
-    if (e == hipSuccess) e = dev_alloc(&tile_batch, static_cast<long long>(T) + 1);
-    if (e == hipSuccess) e = dev_alloc(&cell_slots, cells);
-    if (e == hipSuccess) e = dev_alloc(&offs, cells + 1);
-    if (e == hipSuccess) e = dev_alloc(&strip_begin, S + 1);
-    if (e == hipSuccess) e = dev_alloc(&block_sum, std::max(scan_blocks, tile_scan_blocks) + 2);
+    const long long scan_slots = std::max(scan_blocks, tile_scan_blocks) + 2;
+    first.size = BuildArena::padded(2 * sizeof(int)) + BuildArena::padded((static_cast<size_t>(T) + 1) * sizeof(int)) +
+                 BuildArena::padded(static_cast<size_t>(cells) * sizeof(int)) + BuildArena::padded((static_cast<size_t>(cells) + 1) * sizeof(int)) +
+                 BuildArena::padded(static_cast<size_t>(scan_slots) * sizeof(long long));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&first.base), first.size);
+    if (e == hipSuccess) {
+        d_small = first.take<int>(2);
+        tile_batch = first.take<int>(static_cast<long long>(T) + 1);
+        cell_slots = first.take<int>(cells);
+        offs = first.take<int>(cells + 1);
+        block_sum = first.take<long long>(scan_slots);
+        e = dev_alloc(&strip_begin, S + 1);          // (outlives this function: the fold probe reads it)
+    }
     if (e == hipSuccess) e = hipMemsetAsync(d_small, 0, 2 * sizeof(int), s);
     if (e != hipSuccess) return cleanup(e);
 
@@ -1616,6 +1650,7 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     e = hipMemcpyAsync(&longest, d_small, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return cleanup(e);
+    trace.mark("allocations + longest row");
     const int longest_short = std::min(longest, plan->long_row);
     if (longest_short >= capacity) plan->long_row = capacity / 2;      // (rows that long go the direct way)
     BuildShape sh;
@@ -1636,17 +1671,28 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return cleanup(e);
 
+    trace.mark("batch counts");
     const long long group_count = static_cast<long long>(num_batches) * S;
-    e = dev_alloc(&batch_row, static_cast<long long>(num_batches) + 1);
-    if (e == hipSuccess) e = dev_alloc(&batch_tile, num_batches);
-    if (e == hipSuccess) e = dev_alloc(&groups, group_count);
-    if (e == hipSuccess) e = dev_alloc(&meta, plan->csr_nnz);
+    second.size = BuildArena::padded((static_cast<size_t>(num_batches) + 1) * sizeof(int)) +
+                  BuildArena::padded(static_cast<size_t>(std::max(num_batches, 1)) * sizeof(int)) +
+                  BuildArena::padded(static_cast<size_t>(std::max<long long>(group_count, 1)) * sizeof(uint2)) +
+                  BuildArena::padded(static_cast<size_t>(std::max<long long>(plan->csr_nnz, 1)) * sizeof(unsigned int)) +
+                  BuildArena::padded(static_cast<size_t>(std::max(num_batches, 1)));
+    e = hipMalloc(reinterpret_cast<void**>(&second.base), second.size);
+    if (e == hipSuccess) {
+        batch_row = second.take<int>(static_cast<long long>(num_batches) + 1);
+        batch_tile = second.take<int>(num_batches);
+        groups = second.take<uint2>(group_count);
+        meta = second.take<unsigned int>(plan->csr_nnz);
+        place_todo = second.take<unsigned char>(num_batches);
+    }
     if (e == hipSuccess && has_long_path) {
         e = dev_alloc(&plan->long_rows, plan->csr_nnz / std::max(plan->long_row, 1) + 1);
     }
     if (e != hipSuccess) return cleanup(e);
     batch_rows_kernel<<<T, kBlock, 0, s>>>(dev_src, sh, tile_batch, batch_row, batch_tile);
 
+    trace.mark("allocations (batches)");
     // ---- ranking pass: group sizes + per-entry records; cell placement; scan
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_rank_kernel<Src>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -1667,6 +1713,7 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     if (e == hipSuccess) e = hipMemcpyAsync(&num_long, d_small + 1, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return cleanup(e);
+    trace.mark("ranking + scans (sync)");
     if (totals[0] >= 0x7fffffffLL - 64) return cleanup(hipErrorInvalidValue);       // slot indices are 32-bit
     plan->nnz = totals[0];
     plan->entries = totals[1];
@@ -1683,21 +1730,17 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
         // staged placing pass (contiguous segments); the batches it cannot hold are flagged for the scattered one
         bool staged = true;
         if (const char* env = std::getenv("SPMV_TILED_PLACE")) staged = std::strcmp(env, "scattered") != 0;
-        unsigned char* todo = nullptr;
+        unsigned char* todo = place_todo;
         if (staged) {
             const int stage_slots = (capacity + 1024 + 63) / 64 * 64;
             const size_t stage_lds = static_cast<size_t>(kStageBytesPerStrip) * S + static_cast<size_t>(kStageBytesPerSlot) * stage_slots;
             staged = stage_lds + sizeof(int) * kBuildBlock + 64 <= 160 * 1024;
-            if (staged) e = dev_alloc(&todo, num_batches);
-            if (staged && e == hipSuccess) e = hipMemsetAsync(todo, 0, num_batches, s);
+            if (staged) e = hipMemsetAsync(todo, 0, num_batches, s);
             if (staged && e == hipSuccess) {
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_place_staged_kernel<Src>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(stage_lds));
             }
-            if (e != hipSuccess) {
-                if (todo) (void)hipFree(todo);
-                return cleanup(e);
-            }
+            if (e != hipSuccess) return cleanup(e);
             if (staged) {
                 batch_place_staged_kernel<Src><<<xcd_grid(num_batches), kBuildBlock, stage_lds, s>>>(
                     dev_src, sh, num_batches, capacity, stage_slots, batch_row, batch_tile, groups, meta, offs,
@@ -1707,7 +1750,6 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
         batch_place_kernel<Src><<<xcd_grid(num_batches), kBuildBlock, 12 * static_cast<size_t>(S), s>>>(
             dev_src, sh, num_batches, batch_row, batch_tile, groups, meta, offs, plan->a_val, plan->a_lcol, plan->a_drow,
             staged ? todo : nullptr);
-        place_todo = todo;
         cell_padding_kernel<<<static_cast<int>(std::min<long long>((cells + kBlock - 1) / kBlock, 4096)), kBlock, 0, s>>>(
             cell_slots, offs, cells, plan->a_val, plan->a_lcol, plan->a_drow);
     }
@@ -1721,6 +1763,7 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
                                             hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return cleanup(e);
+    trace.mark("allocations + placing (sync)");
     // strip_begin is needed again by the fold probe: hand it to the plan's scratch (freed by the caller)
     plan->items = strip_begin;          // temporarily; build_plan replaces it
     strip_begin = nullptr;
@@ -1729,6 +1772,7 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
 
 hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     const auto t_begin = std::chrono::steady_clock::now();
+    BuildTrace trace;
     const CSRMatrix* A = src.csr;          // null for an ELL source (then no long-row path)
     *out = nullptr;
     TiledPlan* plan = new TiledPlan();
@@ -1774,6 +1818,7 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         const EllSource dev_src{E->num_rows, E->max_nnz_per_row, E->d_col_indices, E->d_values};
         e = build_cells(dev_src, false, plan, true, &host_strip, s);
     }
+    trace.mark("cells built, temporaries freed");
     int* strip_begin = plan->items;         // parked there by build_cells
     plan->items = nullptr;
     auto fail_with_strip = [&](hipError_t err) {
@@ -1936,6 +1981,7 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     }
     if (e != hipSuccess) return fail(e);
 
+    trace.mark("fold probe, long rows, items");
     plan->plan_bytes = plan->nnz * (4 /*prod*/ + 2 + 1 + (plan->a_val ? 4 : 0)) + cells * 8 +
                        (plan->col_weight ? 4LL * plan->num_cols : 0) +
                        12LL * plan->num_items + 12LL * plan->num_long_chunks;

@@ -208,6 +208,35 @@ constexpr unsigned int kMetaSkip = 0xFFFFFFFFu;
 constexpr int kBuildPerThread = 8;                     // entries a builder thread keeps in registers
 constexpr int kBuildMaxCapacity = kBuildBlock * kBuildPerThread;
 
+// Exclusive scan over the threads of a builder workgroup (1024 = 16 wavefronts) of one non-negative int each —
+// a sum, or a running maximum.  Shuffles inside the wavefronts and 16 wavefront totals through LDS: two barriers
+// where a Hillis-Steele ladder over an LDS array takes twenty (three such scans per batch were about half of a
+// batch's time).  `scratch`: 16 ints of LDS; `*all` receives the total of the whole workgroup.
+template <bool kMax>
+__device__ __forceinline__ int block_exclusive_scan(int own, int* scratch, int* all) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int other = __shfl_up(incl, off, 64);
+        if (lane >= off) incl = kMax ? max(incl, other) : incl + other;
+    }
+    int before = __shfl_up(incl, 1, 64);
+    if (lane == 0) before = 0;
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    int prefix = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBuildBlock / 64; ++w) {
+        const int t = scratch[w];
+        if (w < wave) prefix = kMax ? max(prefix, t) : prefix + t;
+        total = kMax ? max(total, t) : total + t;
+    }
+    __syncthreads();
+    *all = total;
+    return kMax ? max(prefix, before) : prefix + before;
+}
+
 // One batch (consecutive rows of one tile, at most `capacity` short-row entries): bin the entries by strip in
 // LDS, rank every entry inside its bin by (row, column), derive the row deltas and the skip markers they need;
 // report every bin's size and leave the per-entry records.  Dynamic LDS: kBuildBinWords ints per strip, then
@@ -220,7 +249,7 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
                        unsigned int* __restrict__ meta,            // [source entries]
                        int* __restrict__ long_rows, int* __restrict__ num_long) {
     extern __shared__ int build_lds[];
-    __shared__ int s_partial[kBuildBlock];
+    __shared__ int s_partial[kBuildBlock / 64];
     __shared__ int s_row_cache[kBuildRowCache + 1];
     __shared__ int s_overflow;
     const int batch = xcd_contiguous(blockIdx.x, num_batches);
@@ -274,15 +303,8 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
         const int lo = min(span, per * static_cast<int>(threadIdx.x)), hi = min(span, lo + per);
         int best = 0;
         for (int i = lo; i < hi; ++i) best = max(best, static_cast<int>(row_mark[i]));
-        s_partial[threadIdx.x] = best;
-        __syncthreads();
-        for (int off = 1; off < kBuildBlock; off <<= 1) {
-            const int other = static_cast<int>(threadIdx.x) >= off ? s_partial[threadIdx.x - off] : 0;
-            __syncthreads();
-            s_partial[threadIdx.x] = max(s_partial[threadIdx.x], other);
-            __syncthreads();
-        }
-        int run = threadIdx.x ? s_partial[threadIdx.x - 1] : 0;
+        int unused;
+        int run = block_exclusive_scan<true>(best, s_partial, &unused);
         for (int i = lo; i < hi; ++i) {
             run = max(run, static_cast<int>(row_mark[i]));
             row_mark[i] = static_cast<unsigned short>(run);
@@ -364,31 +386,23 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
     __syncthreads();
 
     // ---- exclusive scan of the histogram: every thread owns a contiguous piece of the strips
+    int total = 0;
     {
         const int per = (S + kBuildBlock - 1) / kBuildBlock;
         const int lo = min(S, per * static_cast<int>(threadIdx.x)), hi = min(S, lo + per);
         int sum = 0;
         for (int i = lo; i < hi; ++i) sum += bin_cursor[i];
-        s_partial[threadIdx.x] = sum;
-        __syncthreads();
-        for (int off = 1; off < kBuildBlock; off <<= 1) {
-            const int add = static_cast<int>(threadIdx.x) >= off ? s_partial[threadIdx.x - off] : 0;
-            __syncthreads();
-            s_partial[threadIdx.x] += add;
-            __syncthreads();
-        }
-        int run = threadIdx.x ? s_partial[threadIdx.x - 1] : 0;
+        int run = block_exclusive_scan<false>(sum, s_partial, &total);
         for (int i = lo; i < hi; ++i) {
             const int n = bin_cursor[i];
             bin_start[i] = run;
             bin_cursor[i] = run;
             run += n;
         }
-        if (threadIdx.x == kBuildBlock - 1 && s_partial[kBuildBlock - 1] > capacity) s_overflow = 1;
+        if (threadIdx.x == 0 && total > capacity) s_overflow = 1;
     }
     __syncthreads();
     if (s_overflow) return;          // cannot happen (the batch quota bounds the count); never write past LDS
-    const int total = s_partial[kBuildBlock - 1];
 
     // ---- fill the bins (order inside a bin is arbitrary here; the ranking below fixes it)
     auto put = [&](int c, int lrow, unsigned int from) {
@@ -586,7 +600,7 @@ void batch_place_staged_kernel(Src src, BuildShape sh, int num_batches, int capa
                                float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
                                unsigned char* __restrict__ a_drow, unsigned char* __restrict__ todo) {
     extern __shared__ int stage_lds[];
-    __shared__ int s_partial[kBuildBlock];
+    __shared__ int s_partial[kBuildBlock / 64];
     const int batch = xcd_contiguous(blockIdx.x, num_batches);
     if (batch < 0) return;
     const int S = sh.num_strips;
@@ -659,20 +673,11 @@ void batch_place_staged_kernel(Src src, BuildShape sh, int num_batches, int capa
         const int lo = min(S, per * static_cast<int>(threadIdx.x)), hi = min(S, lo + per);
         int sum = 0;
         for (int i = lo; i < hi; ++i) sum += count[i];
-        s_partial[threadIdx.x] = sum;
-        __syncthreads();
-        for (int off = 1; off < kBuildBlock; off <<= 1) {
-            const int add = static_cast<int>(threadIdx.x) >= off ? s_partial[threadIdx.x - off] : 0;
-            __syncthreads();
-            s_partial[threadIdx.x] += add;
-            __syncthreads();
-        }
-        int run = threadIdx.x ? s_partial[threadIdx.x - 1] : 0;
+        int run = block_exclusive_scan<false>(sum, s_partial, &total);
         for (int i = lo; i < hi; ++i) {
             local[i] = run;
             run += count[i];
         }
-        total = s_partial[kBuildBlock - 1];
     }
     __syncthreads();
     if (total > stage_slots) {                 // (markers galore: more slots than the staging area holds)

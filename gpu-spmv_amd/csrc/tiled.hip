@@ -277,6 +277,13 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
     // thread keeps its entries' columns and rows in registers between the phases, rows come from a scan
     const bool fast = entry1 - entry0 <= capacity;
     const int span = fast ? static_cast<int>(entry1 - entry0) : 0;
+    // the fast path's column loads are issued first: they travel while the rows are being marked and scanned
+    int my_col[kBuildPerThread];
+#pragma unroll
+    for (int u = 0; u < kBuildPerThread; ++u) {
+        const int idx = threadIdx.x + u * kBuildBlock;
+        my_col[u] = idx < span ? src.col(entry0 + idx) : -1;
+    }
 
     for (int i = threadIdx.x; i < S; i += kBuildBlock) {
         bin_cursor[i] = 0;
@@ -355,13 +362,8 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
     };
 
     // ---- histogram of the batch's short-row entries over the strips
-    int my_col[kBuildPerThread], my_lrow[kBuildPerThread];
+    int my_lrow[kBuildPerThread];
     if (fast) {
-#pragma unroll
-        for (int u = 0; u < kBuildPerThread; ++u) {
-            const int idx = threadIdx.x + u * kBuildBlock;
-            my_col[u] = idx < span ? src.col(entry0 + idx) : -1;
-        }
 #pragma unroll
         for (int u = 0; u < kBuildPerThread; ++u) {
             const int idx = threadIdx.x + u * kBuildBlock;

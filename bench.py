@@ -194,40 +194,45 @@ def main():
         ref = after(pr, 4)
         exchange_trials = {"gather_ms_per_step": round(elapsed / args.steps * 1e3, 4), "overlapped": []}
         best = (elapsed, engine, pr, layout, cols_v, exchange)
-        for blocks in candidates:
-            lay2 = prd.Layout(n, world, rank, chunks=blocks, exchange=True)
-            cols2 = torch.empty_like(cols)
-            scratch_ptrs, scratch_vals = torch.empty_like(row_ptrs), torch.empty_like(vals)
-            status = spmv.lib().spmv_c_gen_uniform_rows(args.seed, row_begin, local_rows, n, k, scratch_ptrs.data_ptr(),
-                                                        cols2.data_ptr(), scratch_vals.data_ptr(), stream)   # the node ids again
-            assert status == 0, spmv.spmv_error_string(status)
-            torch.cuda.synchronize()
-            del scratch_ptrs, scratch_vals
-            cols2_v = cols2[: local_rows * k]
-            cols2_v.copy_(lay2.remap_columns(cols2_v))
-            # (its own copy of the row pointers: the library keys a matrix's cached plan by that array)
-            engine2 = prd.HipEngine(row_ptrs.clone(), cols2_v, vals_v, lay2)
-            pr2 = prd.ShardedPageRank(engine2, lay2).prepare()
-            got = after(pr2, 4)
-            worst = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max())
-            agree = torch.tensor([1 if worst <= 1e-5 else 0], dtype=torch.int32, device=device)
-            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-            del got
-            trial = {"blocks": blocks, "max_rel_diff_after_4_steps": worst, "agrees": bool(int(agree.item()))}
-            keep = False
-            if trial["agrees"]:
-                elapsed2 = timed(pr2, engine2)
-                trial["ms_per_step"] = round(elapsed2 / args.steps * 1e3, 4)
-                keep = elapsed2 < best[0]           # the same verdict on every rank (all-reduced maxima)
-            exchange_trials["overlapped"].append(trial)
-            if keep:
-                if best[1] is not engine:           # the plain loop stays until the end (it made `ref`)
-                    best[1].close()
-                    best[2].close()
-                best = (elapsed2, engine2, pr2, lay2, cols2_v, "gather-overlapped x%d" % blocks)
-            else:
-                engine2.close()
-                pr2.close()
+        # Whatever goes wrong in a trial (the same Python exception on every rank — a rank-dependent failure cannot be
+        # caught from here) costs the trial, not the result line: the one-collective measurement above stands.
+        try:
+            for blocks in candidates:
+                lay2 = prd.Layout(n, world, rank, chunks=blocks, exchange=True)
+                cols2 = torch.empty_like(cols)
+                scratch_ptrs, scratch_vals = torch.empty_like(row_ptrs), torch.empty_like(vals)
+                status = spmv.lib().spmv_c_gen_uniform_rows(args.seed, row_begin, local_rows, n, k, scratch_ptrs.data_ptr(),
+                                                            cols2.data_ptr(), scratch_vals.data_ptr(), stream)   # the node ids again
+                assert status == 0, spmv.spmv_error_string(status)
+                torch.cuda.synchronize()
+                del scratch_ptrs, scratch_vals
+                cols2_v = cols2[: local_rows * k]
+                cols2_v.copy_(lay2.remap_columns(cols2_v))
+                # (its own copy of the row pointers: the library keys a matrix's cached plan by that array)
+                engine2 = prd.HipEngine(row_ptrs.clone(), cols2_v, vals_v, lay2)
+                pr2 = prd.ShardedPageRank(engine2, lay2).prepare()
+                got = after(pr2, 4)
+                worst = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max())
+                agree = torch.tensor([1 if worst <= 1e-5 else 0], dtype=torch.int32, device=device)
+                dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+                del got
+                trial = {"blocks": blocks, "max_rel_diff_after_4_steps": worst, "agrees": bool(int(agree.item()))}
+                keep = False
+                if trial["agrees"]:
+                    elapsed2 = timed(pr2, engine2)
+                    trial["ms_per_step"] = round(elapsed2 / args.steps * 1e3, 4)
+                    keep = elapsed2 < best[0]           # the same verdict on every rank (all-reduced maxima)
+                exchange_trials["overlapped"].append(trial)
+                if keep:
+                    if best[1] is not engine:           # the plain loop stays until the end (it made `ref`)
+                        best[1].close()
+                        best[2].close()
+                    best = (elapsed2, engine2, pr2, lay2, cols2_v, "gather-overlapped x%d" % blocks)
+                else:
+                    engine2.close()
+                    pr2.close()
+        except Exception as exc:                                    # noqa: BLE001
+            exchange_trials["aborted"] = repr(exc)
         del ref
         if best[1] is not engine:
             engine.close()

@@ -1,0 +1,746 @@
+// fused_bench.hip — can the product round trip of the two-phase SpMV stay on the die when BOTH phases
+// run inside ONE persistent launch?  (exact occupancy, LDS budget and flag hand-off.)
+//
+// One 1024-thread workgroup per CU holds an x strip (W floats) AND a y tile (R doubles) in LDS.  Its first
+// PW wavefronts are PRODUCERS (phase 1: stage a strip, stream value + local column, gather x from LDS, store
+// the products into a ring slot), the other CW wavefronts are CONSUMERS (phase 2: read one run per strip from
+// the ring + its row deltas, ds_add_f64 into the tile).  Workgroups form TEAMS of G members:
+//   local : a team = the workgroups of one XCD (read from HW_REG_XCC_ID): ring slots are written with plain
+//           stores and read back with sc1 loads — they stay in that XCD's L2; x is re-staged once per
+//           (team, row group): 10 M / (32 * R) groups per XCD.
+//   global: one team of all 256 workgroups: 4 row groups, ring written through (sc1) and read cross-XCD.
+// A team walks its row groups one after the other; per group every strip is one ITEM (split H ways): produced by
+// member (item mod G) into one of its D private ring slots, consumed by the G / H members whose tiles it covers.
+// Flags: ready[item] (producer -> consumers), done[item] (consumers -> the producer that reuses the slot).
+// The synthetic plan has the real engine's layout (cells strip-major, 7 B per slot, runs of ~L slots, multiples
+// of 4) and the result is checked against a plain kernel, every row.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+struct Params {
+    int S, T, R, W, G, H, D, NT, NG, gpt;      // gpt: row groups per team
+    int num_rows, SC;                           // SC: flag words per (group, h, consumer wave)
+    unsigned slot_cap;                          // floats per ring slot
+    unsigned ring_bytes;
+    const float* a_val; const unsigned short* a_lcol; const unsigned char* a_drow;
+    const int2* cells_t;                        // [T * S] tile-major (begin, length)
+    const int2* items;                          // [NG * S * H] (begin, end)
+    const float* x; float* y; float* ring;
+    unsigned* ctl;                              // [0..7] registration per XCC, [8] abort, [9] spin statistics
+    unsigned* ready; unsigned* done;            // per team
+    int items_per_team, ready_per_team;
+    int mode;                                   // 0 normal, 1 producers only, 2 consumers only (timing probes: results meaningless)
+};
+
+constexpr unsigned kSpinLimit = 1u << 20;
+#define RLX __ATOMIC_RELAXED
+#define AGENT __HIP_MEMORY_SCOPE_AGENT
+#define WG __HIP_MEMORY_SCOPE_WORKGROUP
+
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
+// barrier among a subset of the workgroup's wavefronts: monotonic LDS counter, lane 0 of each wave arrives
+__device__ __forceinline__ bool sub_barrier(unsigned* cnt, unsigned target, const unsigned* lds_abort) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, WG);
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, WG) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023) == 0 && __hip_atomic_load(lds_abort, RLX, WG)) return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool spin_until_ge(const unsigned* addr, unsigned target, unsigned* abortw) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(addr, RLX, AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 255) == 0) {
+            if (__hip_atomic_load(abortw, RLX, AGENT)) return false;
+            if (spins > kSpinLimit) { __hip_atomic_store(abortw, 2u, RLX, AGENT); return false; }
+        }
+    }
+    return true;
+}
+
+template <int PW, int CW, bool LOCAL>
+__global__ __launch_bounds__((PW + CW) * 64) void fused(Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* xs = reinterpret_cast<float*>(lds);
+    double* tile = reinterpret_cast<double*>(lds + static_cast<size_t>(p.W) * 4);
+    double* spare = tile + p.R;
+    unsigned* ctl = reinterpret_cast<unsigned*>(spare + 64);     // 0 pbar, 1 cbar, 2 member, 3 team, 4 abort
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) {
+        ctl[0] = 0; ctl[1] = 0; ctl[4] = 0;
+        if (LOCAL) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 0xF;
+            ctl[3] = xcc;
+            ctl[2] = xcc < 8 ? atomicAdd(&p.ctl[xcc], 1u) : 0xFFFFu;
+        } else {
+            ctl[3] = 0;
+            ctl[2] = blockIdx.x;
+        }
+    }
+    __syncthreads();
+    const int member = __builtin_amdgcn_readfirstlane(static_cast<int>(ctl[2]));
+    const int team = __builtin_amdgcn_readfirstlane(static_cast<int>(ctl[3]));
+    unsigned* abortw = p.ctl + 8;
+    if (member >= p.G || team >= p.NT) {         // a placement the schedule was not built for: give up, loudly
+        if (threadIdx.x == 0) __hip_atomic_store(abortw, 3u, RLX, AGENT);
+        return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int S = p.S, H = p.H, G = p.G, D = p.D;
+    unsigned* ready = p.ready + static_cast<size_t>(team) * p.ready_per_team;
+    unsigned* done = p.done + static_cast<size_t>(team) * p.items_per_team;
+    const unsigned consumers_per_item = G / H;
+
+    if (wave < PW) {
+        // ------------------------------------------------------------------ producer
+        if (p.mode == 2) return;
+        const int ptid = threadIdx.x;
+        unsigned phase = 0;
+        const auto ring_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.ring, 0, static_cast<int>(p.ring_bytes), 0x00020000);
+        for (int n = 0;; ++n) {
+            const int j = member + n * G;
+            const int gi = j / (S * H);
+            if (gi >= p.gpt) break;
+            const int g = LOCAL ? team + gi * p.NT : gi;
+            if (g >= p.NG) break;
+            const int rem = j - gi * S * H;
+            const int s = rem / H, h = rem - s * H;
+            const int2 it = p.items[(static_cast<size_t>(g) * S + s) * H + h];
+            // stage the strip (every producer wavefront is past its gathers of the previous item: barrier 2 below)
+            const float* src = p.x + static_cast<size_t>(s) * p.W;
+            for (int i = ptid * 4; i < p.W; i += PW * 64 * 4) {
+                *reinterpret_cast<f32x4*>(xs + i) = *reinterpret_cast<const f32x4*>(src + i);
+            }
+            bool ok = true;
+            if (wave == 0 && n >= D && p.mode == 0) ok = spin_until_ge(done + (j - G * D), consumers_per_item, abortw);   // the slot's previous item is consumed
+            if (!ok) __hip_atomic_store(&ctl[4], 1u, RLX, WG);
+            phase += PW;
+            if (!sub_barrier(&ctl[0], phase, &ctl[4]) || __hip_atomic_load(&ctl[4], RLX, WG)) return;
+            const unsigned slot_base = ((static_cast<unsigned>(team) * G + member) * D + n % D) * p.slot_cap;
+            float* slot = p.ring + slot_base;
+            constexpr int kStep = PW * 64 * 4;
+            constexpr int UN = 4;
+            for (int q0 = it.x + ptid * 4; q0 < it.y; q0 += UN * kStep) {
+                f32x4 v[UN]; u16x4 c[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int q = q0 + u * kStep;
+                    if (q < it.y) {
+                        v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.a_val + q));
+                        c[u] = __builtin_nontemporal_load(reinterpret_cast<const u16x4*>(p.a_lcol + q));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int q = q0 + u * kStep;
+                    if (q < it.y) {
+                        f32x4 r;
+                        r[0] = v[u][0] * xs[c[u][0]]; r[1] = v[u][1] * xs[c[u][1]]; r[2] = v[u][2] * xs[c[u][2]]; r[3] = v[u][3] * xs[c[u][3]];
+                        if (LOCAL) *reinterpret_cast<f32x4*>(slot + (q - it.x)) = r;
+                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), ring_rsrc, (slot_base + (q - it.x)) * 4u, 0, 16);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wavefront drains before the flag
+            phase += PW;
+            if (!sub_barrier(&ctl[0], phase, &ctl[4])) return;
+            if (threadIdx.x == 0) {
+                const int flag = ((gi * H + h) * CW + s % CW) * p.SC + s / CW;
+                __hip_atomic_store(ready + flag, 1u, RLX, AGENT);
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    if (p.mode == 1) return;
+    const int cw = wave - PW;
+    const int ctid = threadIdx.x - PW * 64;
+    const int hme = member / static_cast<int>(consumers_per_item);
+    const auto ring_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.ring, 0, static_cast<int>(p.ring_bytes), 0x00020000);
+    unsigned cphase = 0;
+    for (int i = ctid; i < p.R; i += CW * 64) tile[i] = 0.0;
+    cphase += CW;
+    if (!sub_barrier(&ctl[1], cphase, &ctl[4])) return;
+    const int mine = (S - cw + CW - 1) / CW;         // strips cw, cw + CW, ...
+    unsigned polls = 0;
+    for (int gi = 0; gi < p.gpt; ++gi) {
+        const int g = LOCAL ? team + gi * p.NT : gi;
+        if (g >= p.NG) break;
+        const int t = g * G + member;
+        const bool active = t < p.T;
+        const unsigned* flags = ready + ((gi * H + hme) * CW + cw) * p.SC;
+        // window of 64 of this wavefront's items: lane l holds item k0 + l
+        int k0 = 0, known = p.mode == 2 ? mine : 0, k = 0;
+        int2 cellwin; int itemwin;
+        auto load_window = [&]() {
+            const int kk = k0 + lane;
+            cellwin = make_int2(0, 0); itemwin = 0;
+            if (kk < mine) {
+                const int n = cw + kk * CW;
+                if (active) cellwin = p.cells_t[static_cast<size_t>(t) * S + n];
+                itemwin = p.items[(static_cast<size_t>(g) * S + n) * H + hme].x;
+            }
+        };
+        auto poll = [&]() {          // how many more of the window's items are ready
+            const int kk = k0 + lane;
+            const unsigned f = kk < mine ? __hip_atomic_load(flags + kk, RLX, AGENT) : 0u;
+            const unsigned long long m = __ballot(f != 0);
+            const unsigned long long rest = ~m >> (known - k0);
+            const int run = rest ? __builtin_ctzll(rest) : 64;
+            known = min(known + run, min(mine, k0 + 64));
+            ++polls;
+        };
+        load_window();
+        struct Pass { bool valid, last; int begin, len, off, j; unsigned ringbase; f32x4 prod; unsigned dw; };
+        int cur_begin = 0, cur_len = 0, cur_off = 0, cur_j = 0; unsigned cur_ring = 0;
+        bool aborted = false;
+        // returns false when the next item is not ready yet (non-blocking mode)
+        auto advance = [&](Pass& ps, bool blocking) -> bool {
+            for (;;) {
+                if (cur_off < cur_len) {
+                    ps.valid = true; ps.begin = cur_begin; ps.len = cur_len; ps.off = cur_off; ps.j = cur_j; ps.ringbase = cur_ring;
+                    cur_off += 256;
+                    ps.last = cur_off >= cur_len;
+                    return true;
+                }
+                if (k >= mine) { ps.valid = false; return true; }
+                if (k >= k0 + 64) { k0 += 64; load_window(); }
+                if (k >= known) {
+                    poll();
+                    if (k >= known) {
+                        if (!blocking) return false;
+                        unsigned spins = 0;
+                        while (k >= known) {
+                            __builtin_amdgcn_s_sleep(2);
+                            poll();
+                            if ((++spins & 255) == 0) {
+                                if (__hip_atomic_load(abortw, RLX, AGENT)) { aborted = true; break; }
+                                if (spins > kSpinLimit) { __hip_atomic_store(abortw, 4u, RLX, AGENT); aborted = true; break; }
+                            }
+                        }
+                        if (aborted) { ps.valid = false; return true; }
+                    }
+                }
+                const int idx = __builtin_amdgcn_readfirstlane(k - k0);
+                const int cb = __builtin_amdgcn_readlane(cellwin.x, idx);
+                const int cl = __builtin_amdgcn_readlane(cellwin.y, idx);
+                const int ib = __builtin_amdgcn_readlane(itemwin, idx);
+                const int n = cw + k * CW;
+                const int j = (gi * S + n) * H + hme;
+                ++k;
+                if (cl == 0) {                       // nothing of this tile in the item (or no tile): release at once
+                    if (lane == 0) __hip_atomic_fetch_add(done + j, 1u, RLX, AGENT);
+                    continue;
+                }
+                cur_begin = cb; cur_len = cl; cur_off = 0; cur_j = j;
+                cur_ring = ((static_cast<unsigned>(team) * G + j % G) * D + (j / G) % D) * p.slot_cap + static_cast<unsigned>(cb - ib);
+            }
+        };
+        auto issue = [&](Pass& ps) {
+            const unsigned i = static_cast<unsigned>(ps.off) + 4u * lane;
+            const unsigned at = min(i, static_cast<unsigned>(ps.len - 4));
+            ps.prod = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rsrc, (ps.ringbase + at) * 4u, 0, 16));
+            ps.dw = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p.a_drow + ps.begin + at));
+        };
+        int row_base = 0;
+        auto process = [&](const Pass& ps) {
+            const unsigned i = static_cast<unsigned>(ps.off) + 4u * lane;
+            if (ps.off == 0) row_base = 0;
+            const unsigned word = i < static_cast<unsigned>(ps.len) ? ps.dw : 0xFFFFFFFFu;
+            int delta[4], upto[4], sum = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { delta[e] = (word >> (8 * e)) & 0xFF; sum += delta[e]; upto[e] = sum; }
+            const int incl = wave_inclusive_scan(sum);
+            const int lane_base = row_base + incl - sum;
+            row_base += __builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double* target = delta[e] != 255 ? &tile[lane_base + upto[e]] : &spare[lane];
+                atomicAdd(target, static_cast<double>(ps.prod[e]));
+            }
+            if (ps.last) {                           // the run's products are in registers: its slot share may be reused
+                asm volatile("" :: "v"(ps.prod[0]) : "memory");
+                if (lane == 0) __hip_atomic_fetch_add(done + ps.j, 1u, RLX, AGENT);
+            }
+        };
+        // P passes in flight per wavefront.  Pass i of the stream always sits in slot i mod P, so the round-robin
+        // visit processes the passes in stream order (a run's row base carries from pass to pass).  When the next
+        // item is not ready, nothing more is fetched; the slots in flight drain and a new EPOCH starts with slot 0
+        // waiting for that item — a wavefront never waits while it holds unprocessed (unreleased) products.
+        constexpr int P = 4;
+        Pass ps[P];
+        int state[P];                                 // 1: loads issued, 2: empty
+        for (bool ended = false; !ended && !aborted;) {
+            bool stalled = false;
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                state[u] = 2;
+                if (stalled) continue;
+                const bool got = advance(ps[u], u == 0);
+                if (!got) { stalled = true; continue; }
+                if (!ps[u].valid) { stalled = true; ended = true; continue; }
+                issue(ps[u]);
+                state[u] = 1;
+            }
+            for (bool run = state[0] == 1; run;) {
+#pragma unroll
+                for (int u = 0; u < P; ++u) {
+                    if (state[u] != 1) { run = false; break; }
+                    process(ps[u]);
+                    state[u] = 2;
+                    if (stalled) continue;
+                    const bool got = advance(ps[u], false);
+                    if (!got) { stalled = true; continue; }
+                    if (!ps[u].valid) { stalled = true; ended = true; continue; }
+                    issue(ps[u]);
+                    state[u] = 1;
+                }
+            }
+        }
+        if (aborted) { __hip_atomic_store(&ctl[4], 1u, RLX, WG); }
+        cphase += CW;
+        if (!sub_barrier(&ctl[1], cphase, &ctl[4]) || __hip_atomic_load(&ctl[4], RLX, WG)) return;
+        for (int i = ctid; i < p.R; i += CW * 64) {
+            const long long row = static_cast<long long>(t) * p.R + i;
+            if (active && row < p.num_rows) p.y[row] = static_cast<float>(tile[i]);
+            tile[i] = 0.0;
+        }
+        cphase += CW;
+        if (!sub_barrier(&ctl[1], cphase, &ctl[4])) return;
+    }
+    if (lane == 0) atomicAdd(&p.ctl[9], polls);
+}
+
+// ------------------------------------------------------------------------------------------ split roles
+// Two 1024-thread workgroups per CU (LDS max(W * 4, R * 8) each): the first to arrive on a CU (per-CU counter keyed by
+// XCC_ID and HW_ID's SE/SH/CU fields) becomes a CONSUMER, the second a PRODUCER, so every CU's LDS pipe carries one
+// tile's adds and one strip's gathers; sixteen wavefronts per role, hardware barriers inside a role.  One team of all
+// CUs ("global"): ring written through (sc1 stores), read with sc1 loads.
+template <int P>
+__global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    __shared__ unsigned sh[4];
+    const int lane = threadIdx.x & 63;
+    unsigned* abortw = p.ctl + 8;
+    if (threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const unsigned cu = ((xcc & 0xF) << 8) | ((hw >> 8) & 0xFF);
+        const unsigned arrival = atomicAdd(&p.ctl[16 + cu], 1u);
+        const unsigned role = arrival & 1;                       // 0 consumer, 1 producer
+        sh[0] = role; sh[2] = 0; sh[3] = 0;
+        sh[1] = atomicAdd(&p.ctl[10 + role], 1u);                // index inside the role
+    }
+    __syncthreads();
+    const int role = __builtin_amdgcn_readfirstlane(static_cast<int>(sh[0]));
+    const int member = __builtin_amdgcn_readfirstlane(static_cast<int>(sh[1]));
+    if (member >= p.G) {
+        if (threadIdx.x == 0) __hip_atomic_store(abortw, 3u, RLX, AGENT);
+        return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int S = p.S, H = p.H, G = p.G, D = p.D;
+    constexpr int CW = 16;
+    unsigned* ready = p.ready;
+    unsigned* done = p.done;
+    const unsigned consumers_per_item = G / H;
+    const auto ring_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.ring, 0, static_cast<int>(p.ring_bytes), 0x00020000);
+
+    if (role == 1) {
+        if (p.mode == 2) return;
+        float* xs = reinterpret_cast<float*>(lds);
+        const int ptid = threadIdx.x;
+        for (int n = 0;; ++n) {
+            const int j = member + n * G;
+            const int gi = j / (S * H);
+            if (gi >= p.NG) break;
+            const int rem = j - gi * S * H;
+            const int s = rem / H, h = rem - s * H;
+            const int2 it = p.items[(static_cast<size_t>(gi) * S + s) * H + h];
+            const float* src = p.x + static_cast<size_t>(s) * p.W;
+            for (int i = ptid * 4; i < p.W; i += 1024 * 4) {
+                *reinterpret_cast<f32x4*>(xs + i) = *reinterpret_cast<const f32x4*>(src + i);
+            }
+            if (wave == 0 && n >= D && p.mode == 0) {
+                if (!spin_until_ge(done + (j - G * D), consumers_per_item, abortw)) sh[2] = 1;
+            }
+            __syncthreads();
+            if (sh[2]) return;
+            const unsigned slot_base = (static_cast<unsigned>(member) * D + n % D) * p.slot_cap;
+            constexpr int kStep = 1024 * 4;
+            constexpr int UN = 4;
+            for (int q0 = it.x + ptid * 4; q0 < it.y; q0 += UN * kStep) {
+                f32x4 v[UN]; u16x4 c[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int q = q0 + u * kStep;
+                    if (q < it.y) {
+                        v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.a_val + q));
+                        c[u] = __builtin_nontemporal_load(reinterpret_cast<const u16x4*>(p.a_lcol + q));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int q = q0 + u * kStep;
+                    if (q < it.y) {
+                        f32x4 r;
+                        r[0] = v[u][0] * xs[c[u][0]]; r[1] = v[u][1] * xs[c[u][1]]; r[2] = v[u][2] * xs[c[u][2]]; r[3] = v[u][3] * xs[c[u][3]];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), ring_rsrc, (slot_base + (q - it.x)) * 4u, 0, 16);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int flag = ((gi * H + h) * CW + s % CW) * p.SC + s / CW;
+                __hip_atomic_store(ready + flag, 1u, RLX, AGENT);
+            }
+        }
+        return;
+    }
+
+    if (p.mode == 1) return;
+    double* tile = reinterpret_cast<double*>(lds);
+    __shared__ double spare[64];
+    const int cw = wave;
+    const int hme = member / static_cast<int>(consumers_per_item);
+    for (int i = threadIdx.x; i < p.R; i += 1024) tile[i] = 0.0;
+    __syncthreads();
+    const int mine = (S - cw + CW - 1) / CW;
+    unsigned polls = 0;
+    for (int gi = 0; gi < p.NG; ++gi) {
+        const int t = gi * G + member;
+        const bool active = t < p.T;
+        const unsigned* flags = ready + ((gi * H + hme) * CW + cw) * p.SC;
+        int k0 = 0, known = p.mode == 2 ? mine : 0, k = 0;
+        int2 cellwin; int itemwin;
+        auto load_window = [&]() {
+            const int kk = k0 + lane;
+            cellwin = make_int2(0, 0); itemwin = 0;
+            if (kk < mine) {
+                const int n = cw + kk * CW;
+                if (active) cellwin = p.cells_t[static_cast<size_t>(t) * S + n];
+                itemwin = p.items[(static_cast<size_t>(gi) * S + n) * H + hme].x;
+            }
+        };
+        auto poll = [&]() {
+            const int kk = k0 + lane;
+            const unsigned f = kk < mine ? __hip_atomic_load(flags + kk, RLX, AGENT) : 0u;
+            const unsigned long long m = __ballot(f != 0);
+            const unsigned long long rest = ~m >> (known - k0);
+            const int run = rest ? __builtin_ctzll(rest) : 64;
+            known = min(known + run, min(mine, k0 + 64));
+            ++polls;
+        };
+        load_window();
+        struct Pass { bool valid, last; int begin, len, off, j; unsigned ringbase; f32x4 prod; unsigned dw; };
+        int cur_begin = 0, cur_len = 0, cur_off = 0, cur_j = 0; unsigned cur_ring = 0;
+        bool aborted = false;
+        auto advance = [&](Pass& ps, bool blocking) -> bool {
+            for (;;) {
+                if (cur_off < cur_len) {
+                    ps.valid = true; ps.begin = cur_begin; ps.len = cur_len; ps.off = cur_off; ps.j = cur_j; ps.ringbase = cur_ring;
+                    cur_off += 256;
+                    ps.last = cur_off >= cur_len;
+                    return true;
+                }
+                if (k >= mine) { ps.valid = false; return true; }
+                if (k >= k0 + 64) { k0 += 64; load_window(); }
+                if (k >= known) {
+                    poll();
+                    if (k >= known) {
+                        if (!blocking) return false;
+                        unsigned spins = 0;
+                        while (k >= known) {
+                            __builtin_amdgcn_s_sleep(2);
+                            poll();
+                            if ((++spins & 255) == 0) {
+                                if (__hip_atomic_load(abortw, RLX, AGENT)) { aborted = true; break; }
+                                if (spins > kSpinLimit) { __hip_atomic_store(abortw, 4u, RLX, AGENT); aborted = true; break; }
+                            }
+                        }
+                        if (aborted) { ps.valid = false; return true; }
+                    }
+                }
+                const int idx = __builtin_amdgcn_readfirstlane(k - k0);
+                const int cb = __builtin_amdgcn_readlane(cellwin.x, idx);
+                const int cl = __builtin_amdgcn_readlane(cellwin.y, idx);
+                const int ib = __builtin_amdgcn_readlane(itemwin, idx);
+                const int n = cw + k * CW;
+                const int j = (gi * S + n) * H + hme;
+                ++k;
+                if (cl == 0) {
+                    if (lane == 0) __hip_atomic_fetch_add(done + j, 1u, RLX, AGENT);
+                    continue;
+                }
+                cur_begin = cb; cur_len = cl; cur_off = 0; cur_j = j;
+                cur_ring = (static_cast<unsigned>(j % G) * D + (j / G) % D) * p.slot_cap + static_cast<unsigned>(cb - ib);
+            }
+        };
+        auto issue = [&](Pass& ps) {
+            const unsigned i = static_cast<unsigned>(ps.off) + 4u * lane;
+            const unsigned at = min(i, static_cast<unsigned>(ps.len - 4));
+            ps.prod = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rsrc, (ps.ringbase + at) * 4u, 0, 16));
+            ps.dw = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p.a_drow + ps.begin + at));
+        };
+        int row_base = 0;
+        auto process = [&](const Pass& ps) {
+            const unsigned i = static_cast<unsigned>(ps.off) + 4u * lane;
+            if (ps.off == 0) row_base = 0;
+            const unsigned word = i < static_cast<unsigned>(ps.len) ? ps.dw : 0xFFFFFFFFu;
+            int delta[4], upto[4], sum = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { delta[e] = (word >> (8 * e)) & 0xFF; sum += delta[e]; upto[e] = sum; }
+            const int incl = wave_inclusive_scan(sum);
+            const int lane_base = row_base + incl - sum;
+            row_base += __builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double* target = delta[e] != 255 ? &tile[lane_base + upto[e]] : &spare[lane];
+                atomicAdd(target, static_cast<double>(ps.prod[e]));
+            }
+            if (ps.last) {
+                asm volatile("" :: "v"(ps.prod[0]) : "memory");
+                if (lane == 0) __hip_atomic_fetch_add(done + ps.j, 1u, RLX, AGENT);
+            }
+        };
+        Pass ps[P];
+        int state[P];
+        for (bool ended = false; !ended && !aborted;) {
+            bool stalled = false;
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                state[u] = 2;
+                if (stalled) continue;
+                const bool got = advance(ps[u], u == 0);
+                if (!got) { stalled = true; continue; }
+                if (!ps[u].valid) { stalled = true; ended = true; continue; }
+                issue(ps[u]);
+                state[u] = 1;
+            }
+            for (bool run = state[0] == 1; run;) {
+#pragma unroll
+                for (int u = 0; u < P; ++u) {
+                    if (state[u] != 1) { run = false; break; }
+                    process(ps[u]);
+                    state[u] = 2;
+                    if (stalled) continue;
+                    const bool got = advance(ps[u], false);
+                    if (!got) { stalled = true; continue; }
+                    if (!ps[u].valid) { stalled = true; ended = true; continue; }
+                    issue(ps[u]);
+                    state[u] = 1;
+                }
+            }
+        }
+        if (aborted) sh[3] = 1;
+        __syncthreads();
+        if (sh[3]) return;
+        for (int i = threadIdx.x; i < p.R; i += 1024) {
+            const long long row = static_cast<long long>(t) * p.R + i;
+            if (active && row < p.num_rows) p.y[row] = static_cast<float>(tile[i]);
+            tile[i] = 0.0;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) atomicAdd(&p.ctl[9], polls);
+}
+
+// ------------------------------------------------------------------------------------------ synthetic plan
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z *= 0x9E3779B97F4A7C15ull; z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32; return z;
+}
+__global__ void fill_cells(const int* begin, const int* len, long long cells, int T, int R, int W,
+                           float* a_val, unsigned short* a_lcol, unsigned char* a_drow) {
+    // one wavefront-sized group of threads per cell would be nicer; this runs once
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (long long)gridDim.x * blockDim.x) {
+        const int b = begin[c], l = len[c];
+        const int dmax = R / (l + 1);
+        for (int i = 0; i < l; ++i) {
+            const unsigned long long z = mix64((unsigned long long)(b + i) + 12345);
+            a_val[b + i] = 0.5f + (float)(z & 1023) * (1.0f / 1024.0f);
+            a_lcol[b + i] = (unsigned short)((z >> 10) % W);
+            a_drow[b + i] = (unsigned char)((z >> 40) % dmax);
+        }
+    }
+}
+__global__ void fill_x(float* x, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        x[i] = 0.25f + (float)(mix64(i + 777) & 255) * (1.0f / 256.0f);
+}
+// plain evaluation of the same plan: one thread per cell, global double atomics
+__global__ void reference(const int* begin, const int* len, long long cells, int T, int R, int W,
+                          const float* a_val, const unsigned short* a_lcol, const unsigned char* a_drow,
+                          const float* x, double* yref) {
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (long long)gridDim.x * blockDim.x) {
+        const int s = (int)(c / T), t = (int)(c % T);
+        const int b = begin[c], l = len[c];
+        int row = 0;
+        for (int i = 0; i < l; ++i) {
+            row += a_drow[b + i];
+            if (a_drow[b + i] == 255) continue;
+            atomicAdd(&yref[(long long)t * R + row], (double)(a_val[b + i] * x[(long long)s * W + a_lcol[b + i]]));
+        }
+    }
+}
+__global__ void compare(const float* y, const double* yref, long long n, unsigned long long* bad, double* worst) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double want = yref[i];
+        const double err = fabs((double)y[i] - want) / fmax(fabs(want), 1e-30);
+        if (!(err <= 1e-6) && !(want == 0.0 && y[i] == 0.0f)) atomicAdd(bad, 1ull);
+    }
+}
+
+int main(int argc, char** argv) {
+    // fused_bench <local|global> W R D H PW [L] [reps]
+    const bool local = argc > 1 ? strcmp(argv[1], "local") == 0 : true;
+    const bool split = argc > 1 && strcmp(argv[1], "split") == 0;        // two workgroups per CU, one per role; PW = passes in flight
+    const int W = argc > 2 ? atoi(argv[2]) : 16384;
+    const int R = argc > 3 ? atoi(argv[3]) : 9792;
+    const int D = argc > 4 ? atoi(argv[4]) : 2;
+    const int H = argc > 5 ? atoi(argv[5]) : 1;
+    const int PW = argc > 6 ? atoi(argv[6]) : 8;
+    const int reps = argc > 7 ? atoi(argv[7]) : 5;
+    const int mode = argc > 8 ? atoi(argv[8]) : 0;
+    const long long rows = 10000000, cols = 10000000, entries = 160000000;
+    const int S = (int)((cols + W - 1) / W), T = (int)((rows + R - 1) / R);
+    const int L = (int)(entries / ((long long)S * T));         // mean run length
+    hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const int NT = local ? 8 : 1, G = cus / NT;
+    if (G % H) { printf("G %% H != 0\n"); return 1; }
+    const int NG = (T + G - 1) / G, gpt = (NG + NT - 1) / NT;
+    const int CW = split ? 16 : 16 - PW;
+    const int SC = (S + CW - 1) / CW;
+
+    // cells: strip-major, lengths multiples of 4 around L
+    const long long cells = (long long)S * T;
+    std::vector<int> len(cells), begin(cells + 1);
+    long long total = 0;
+    for (long long c = 0; c < cells; ++c) {
+        unsigned long long z = (unsigned long long)c * 0x9E3779B97F4A7C15ull; z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
+        int l = L + (int)(z % 65) - 32;             // +-32 around the mean (sqrt(256) = 16: two sigma)
+        l = std::max(4, (l + 3) / 4 * 4);
+        len[c] = l; begin[c] = (int)total; total += l;
+    }
+    begin[cells] = (int)total;
+    std::vector<int2> cells_t((size_t)T * S), items((size_t)NG * S * H);
+    for (int t = 0; t < T; ++t) for (int s = 0; s < S; ++s) cells_t[(size_t)t * S + s] = make_int2(begin[(long long)s * T + t], len[(long long)s * T + t]);
+    unsigned slot_cap = 0;
+    for (int g = 0; g < NG; ++g) for (int s = 0; s < S; ++s) for (int h = 0; h < H; ++h) {
+        const int lo = std::min(T, g * G + h * (G / H)), hi = std::min(T, g * G + (h + 1) * (G / H));
+        const int b = begin[(long long)s * T + lo], e = begin[(long long)s * T + hi];
+        items[((size_t)g * S + s) * H + h] = make_int2(b, e);
+        slot_cap = std::max(slot_cap, (unsigned)(e - b));
+    }
+    slot_cap = (slot_cap + 63) / 64 * 64;
+    const size_t ring_floats = (size_t)NT * G * D * slot_cap;
+    if (ring_floats * 4 >= (1ull << 32)) { printf("ring too large\n"); return 1; }
+    const int items_per_team = gpt * S * H, ready_per_team = gpt * H * CW * SC;
+
+    printf("%s  W %d R %d  S %d T %d  run %d  G %d H %d D %d  groups %d (%d per team)  PW %d CW %d  slots %lld  item <= %u slots  ring %.1f MB  LDS %d B\n",
+           split ? "split " : local ? "local " : "global", W, R, S, T, L, G, H, D, NG, gpt, PW, CW, total, slot_cap, ring_floats * 4 / 1048576.0, W * 4 + R * 8 + 512 + 64);
+    fflush(stdout);
+
+    float *a_val, *x, *y, *ring; unsigned short* a_lcol; unsigned char* a_drow; int *d_begin, *d_len; int2 *d_cells_t, *d_items;
+    double* yref; unsigned* flags; unsigned long long* bad;
+    CHECK(hipMalloc(&a_val, total * 4 + 64)); CHECK(hipMalloc(&a_lcol, total * 2 + 64)); CHECK(hipMalloc(&a_drow, total + 64));
+    CHECK(hipMalloc(&x, (size_t)S * W * 4)); CHECK(hipMalloc(&y, (size_t)T * R * 4)); CHECK(hipMalloc(&yref, (size_t)T * R * 8));
+    CHECK(hipMalloc(&ring, ring_floats * 4)); CHECK(hipMalloc(&d_begin, (cells + 1) * 4)); CHECK(hipMalloc(&d_len, cells * 4));
+    CHECK(hipMalloc(&d_cells_t, cells_t.size() * 8)); CHECK(hipMalloc(&d_items, items.size() * 8));
+    const size_t ctl_words = 16 + 4096;                      // registration, abort, statistics; per-CU arrival counters
+    const size_t flag_words = ctl_words + (size_t)NT * (items_per_team + ready_per_team);
+    CHECK(hipMalloc(&flags, flag_words * 4)); CHECK(hipMalloc(&bad, 8));
+    CHECK(hipMemcpy(d_begin, begin.data(), (cells + 1) * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_len, len.data(), cells * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_cells_t, cells_t.data(), cells_t.size() * 8, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_items, items.data(), items.size() * 8, hipMemcpyHostToDevice));
+    fill_cells<<<2048, 256>>>(d_begin, d_len, cells, T, R, W, a_val, a_lcol, a_drow);
+    fill_x<<<2048, 256>>>(x, (long long)S * W);
+    CHECK(hipMemset(yref, 0, (size_t)T * R * 8)); CHECK(hipMemset(ring, 0, ring_floats * 4));
+    reference<<<4096, 256>>>(d_begin, d_len, cells, T, R, W, a_val, a_lcol, a_drow, x, yref);
+    CHECK(hipDeviceSynchronize());
+
+    Params p{};
+    p.S = S; p.T = T; p.R = R; p.W = W; p.G = G; p.H = H; p.D = D; p.NT = NT; p.NG = NG; p.gpt = gpt;
+    p.num_rows = (int)rows; p.SC = SC; p.slot_cap = slot_cap; p.ring_bytes = (unsigned)(ring_floats * 4);
+    p.a_val = a_val; p.a_lcol = a_lcol; p.a_drow = a_drow; p.cells_t = d_cells_t; p.items = d_items; p.x = x; p.y = y; p.ring = ring;
+    p.ctl = flags; p.done = flags + ctl_words; p.ready = flags + ctl_words + (size_t)NT * items_per_team;
+    p.items_per_team = items_per_team; p.ready_per_team = ready_per_team; p.mode = 0;
+    const size_t lds = split ? std::max((size_t)W * 4, (size_t)R * 8) : (size_t)W * 4 + (size_t)R * 8 + 512 + 64;
+
+    auto launch = [&]() {
+        CHECK(hipMemsetAsync(flags, 0, flag_words * 4, 0));
+#define GO(PWV, LOC) do { auto kern = fused<PWV, 16 - PWV, LOC>; \
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        kern<<<cus, 1024, lds, 0>>>(p); } while (0)
+        if (split) {
+#define GOS(PV) do { auto kern = fused_split<PV>; \
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        kern<<<2 * cus, 1024, lds, 0>>>(p); } while (0)
+            if (PW == 1) GOS(1); else if (PW == 2) GOS(2); else if (PW == 3) GOS(3); else GOS(4);
+        } else if (local) { if (PW == 8) GO(8, true); else if (PW == 6) GO(6, true); else if (PW == 4) GO(4, true); else GO(10, true); }
+        else       { if (PW == 8) GO(8, false); else if (PW == 6) GO(6, false); else if (PW == 4) GO(4, false); else GO(10, false); }
+        CHECK(hipGetLastError());
+    };
+    CHECK(hipMemset(y, 0xFF, (size_t)T * R * 4));
+    launch();
+    CHECK(hipDeviceSynchronize());
+    unsigned ctl_host[16];
+    CHECK(hipMemcpy(ctl_host, flags, 64, hipMemcpyDeviceToHost));
+    printf("registration per XCC: %u %u %u %u %u %u %u %u  consumers %u producers %u  abort %u\n", ctl_host[0], ctl_host[1], ctl_host[2], ctl_host[3], ctl_host[4],
+           ctl_host[5], ctl_host[6], ctl_host[7], ctl_host[10], ctl_host[11], ctl_host[8]);
+    if (ctl_host[8]) { printf("ABORTED (code %u)\n", ctl_host[8]); return 2; }
+    CHECK(hipMemset(bad, 0, 8));
+    compare<<<2048, 256>>>(y, yref, rows, bad, nullptr);
+    unsigned long long bad_host = 0;
+    CHECK(hipMemcpy(&bad_host, bad, 8, hipMemcpyDeviceToHost));
+    printf("rows differing from the plain evaluation: %llu of %lld\n", bad_host, rows);
+    fflush(stdout);
+
+    p.mode = mode;
+    if (mode) printf("PROBE mode %d (%s only): results are not checked\n", mode, mode == 1 ? "producers" : "consumers");
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float best = 1e9f, sum = 0;
+    for (int r = 0; r < reps; ++r) {
+        CHECK(hipEventRecord(e0));
+        launch();
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms); sum += ms;
+    }
+    CHECK(hipMemcpy(ctl_host, flags, 64, hipMemcpyDeviceToHost));
+    CHECK(hipMemset(bad, 0, 8));
+    compare<<<2048, 256>>>(y, yref, rows, bad, nullptr);
+    CHECK(hipMemcpy(&bad_host, bad, 8, hipMemcpyDeviceToHost));
+    const double alg = 1.400000004e9;
+    printf("fused step (memset + kernel): avg %.1f us  best %.1f us  => %.3f of 8 TB/s on 1.40 GB algorithmic | polls per consumer wave %.1f | abort %u | bad rows after timing %llu\n",
+           sum / reps * 1e3, best * 1e3, alg / (best * 1e-3) / 8e12, ctl_host[9] / (double)(cus * CW), ctl_host[8], bad_host);
+    return 0;
+}

@@ -43,6 +43,7 @@ struct Params {
 };
 
 constexpr unsigned kSpinLimit = 1u << 20;
+constexpr int kDoneStride = 64;               // one done counter per 256 bytes: the adds of different items meet in different channels
 #define RLX __ATOMIC_RELAXED
 #define AGENT __HIP_MEMORY_SCOPE_AGENT
 #define WG __HIP_MEMORY_SCOPE_WORKGROUP
@@ -80,268 +81,14 @@ __device__ __forceinline__ bool spin_until_ge(const unsigned* addr, unsigned tar
     return true;
 }
 
-template <int PW, int CW, bool LOCAL>
-__global__ __launch_bounds__((PW + CW) * 64) void fused(Params p) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    float* xs = reinterpret_cast<float*>(lds);
-    double* tile = reinterpret_cast<double*>(lds + static_cast<size_t>(p.W) * 4);
-    double* spare = tile + p.R;
-    unsigned* ctl = reinterpret_cast<unsigned*>(spare + 64);     // 0 pbar, 1 cbar, 2 member, 3 team, 4 abort
-    const int lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) {
-        ctl[0] = 0; ctl[1] = 0; ctl[4] = 0;
-        if (LOCAL) {
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            xcc &= 0xF;
-            ctl[3] = xcc;
-            ctl[2] = xcc < 8 ? atomicAdd(&p.ctl[xcc], 1u) : 0xFFFFu;
-        } else {
-            ctl[3] = 0;
-            ctl[2] = blockIdx.x;
-        }
-    }
-    __syncthreads();
-    const int member = __builtin_amdgcn_readfirstlane(static_cast<int>(ctl[2]));
-    const int team = __builtin_amdgcn_readfirstlane(static_cast<int>(ctl[3]));
-    unsigned* abortw = p.ctl + 8;
-    if (member >= p.G || team >= p.NT) {         // a placement the schedule was not built for: give up, loudly
-        if (threadIdx.x == 0) __hip_atomic_store(abortw, 3u, RLX, AGENT);
-        return;
-    }
-    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    const int S = p.S, H = p.H, G = p.G, D = p.D;
-    unsigned* ready = p.ready + static_cast<size_t>(team) * p.ready_per_team;
-    unsigned* done = p.done + static_cast<size_t>(team) * p.items_per_team;
-    const unsigned consumers_per_item = G / H;
-
-    if (wave < PW) {
-        // ------------------------------------------------------------------ producer
-        if (p.mode == 2) return;
-        const int ptid = threadIdx.x;
-        unsigned phase = 0;
-        const auto ring_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.ring, 0, static_cast<int>(p.ring_bytes), 0x00020000);
-        for (int n = 0;; ++n) {
-            const int j = member + n * G;
-            const int gi = j / (S * H);
-            if (gi >= p.gpt) break;
-            const int g = LOCAL ? team + gi * p.NT : gi;
-            if (g >= p.NG) break;
-            const int rem = j - gi * S * H;
-            const int s = rem / H, h = rem - s * H;
-            const int2 it = p.items[(static_cast<size_t>(g) * S + s) * H + h];
-            // stage the strip (every producer wavefront is past its gathers of the previous item: barrier 2 below)
-            const float* src = p.x + static_cast<size_t>(s) * p.W;
-            for (int i = ptid * 4; i < p.W; i += PW * 64 * 4) {
-                *reinterpret_cast<f32x4*>(xs + i) = *reinterpret_cast<const f32x4*>(src + i);
-            }
-            bool ok = true;
-            if (wave == 0 && n >= D && p.mode == 0) ok = spin_until_ge(done + (j - G * D), consumers_per_item, abortw);   // the slot's previous item is consumed
-            if (!ok) __hip_atomic_store(&ctl[4], 1u, RLX, WG);
-            phase += PW;
-            if (!sub_barrier(&ctl[0], phase, &ctl[4]) || __hip_atomic_load(&ctl[4], RLX, WG)) return;
-            const unsigned slot_base = ((static_cast<unsigned>(team) * G + member) * D + n % D) * p.slot_cap;
-            float* slot = p.ring + slot_base;
-            constexpr int kStep = PW * 64 * 4;
-            constexpr int UN = 4;
-            for (int q0 = it.x + ptid * 4; q0 < it.y; q0 += UN * kStep) {
-                f32x4 v[UN]; u16x4 c[UN];
-#pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    const int q = q0 + u * kStep;
-                    if (q < it.y) {
-                        v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.a_val + q));
-                        c[u] = __builtin_nontemporal_load(reinterpret_cast<const u16x4*>(p.a_lcol + q));
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    const int q = q0 + u * kStep;
-                    if (q < it.y) {
-                        f32x4 r;
-                        r[0] = v[u][0] * xs[c[u][0]]; r[1] = v[u][1] * xs[c[u][1]]; r[2] = v[u][2] * xs[c[u][2]]; r[3] = v[u][3] * xs[c[u][3]];
-                        if (LOCAL) *reinterpret_cast<f32x4*>(slot + (q - it.x)) = r;
-                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), ring_rsrc, (slot_base + (q - it.x)) * 4u, 0, 16);
-                    }
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wavefront drains before the flag
-            phase += PW;
-            if (!sub_barrier(&ctl[0], phase, &ctl[4])) return;
-            if (threadIdx.x == 0) {
-                const int flag = ((gi * H + h) * CW + s % CW) * p.SC + s / CW;
-                __hip_atomic_store(ready + flag, 1u, RLX, AGENT);
-            }
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- consumer
-    if (p.mode == 1) return;
-    const int cw = wave - PW;
-    const int ctid = threadIdx.x - PW * 64;
-    const int hme = member / static_cast<int>(consumers_per_item);
-    const auto ring_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.ring, 0, static_cast<int>(p.ring_bytes), 0x00020000);
-    unsigned cphase = 0;
-    for (int i = ctid; i < p.R; i += CW * 64) tile[i] = 0.0;
-    cphase += CW;
-    if (!sub_barrier(&ctl[1], cphase, &ctl[4])) return;
-    const int mine = (S - cw + CW - 1) / CW;         // strips cw, cw + CW, ...
-    unsigned polls = 0;
-    for (int gi = 0; gi < p.gpt; ++gi) {
-        const int g = LOCAL ? team + gi * p.NT : gi;
-        if (g >= p.NG) break;
-        const int t = g * G + member;
-        const bool active = t < p.T;
-        const unsigned* flags = ready + ((gi * H + hme) * CW + cw) * p.SC;
-        // window of 64 of this wavefront's items: lane l holds item k0 + l
-        int k0 = 0, known = p.mode == 2 ? mine : 0, k = 0;
-        int2 cellwin; int itemwin;
-        auto load_window = [&]() {
-            const int kk = k0 + lane;
-            cellwin = make_int2(0, 0); itemwin = 0;
-            if (kk < mine) {
-                const int n = cw + kk * CW;
-                if (active) cellwin = p.cells_t[static_cast<size_t>(t) * S + n];
-                itemwin = p.items[(static_cast<size_t>(g) * S + n) * H + hme].x;
-            }
-        };
-        auto poll = [&]() {          // how many more of the window's items are ready
-            const int kk = k0 + lane;
-            const unsigned f = kk < mine ? __hip_atomic_load(flags + kk, RLX, AGENT) : 0u;
-            const unsigned long long m = __ballot(f != 0);
-            const unsigned long long rest = ~m >> (known - k0);
-            const int run = rest ? __builtin_ctzll(rest) : 64;
-            known = min(known + run, min(mine, k0 + 64));
-            ++polls;
-        };
-        load_window();
-        struct Pass { bool valid, last; int begin, len, off, j; unsigned ringbase; f32x4 prod; unsigned dw; };
-        int cur_begin = 0, cur_len = 0, cur_off = 0, cur_j = 0; unsigned cur_ring = 0;
-        bool aborted = false;
-        // returns false when the next item is not ready yet (non-blocking mode)
-        auto advance = [&](Pass& ps, bool blocking) -> bool {
-            for (;;) {
-                if (cur_off < cur_len) {
-                    ps.valid = true; ps.begin = cur_begin; ps.len = cur_len; ps.off = cur_off; ps.j = cur_j; ps.ringbase = cur_ring;
-                    cur_off += 256;
-                    ps.last = cur_off >= cur_len;
-                    return true;
-                }
-                if (k >= mine) { ps.valid = false; return true; }
-                if (k >= k0 + 64) { k0 += 64; load_window(); }
-                if (k >= known) {
-                    poll();
-                    if (k >= known) {
-                        if (!blocking) return false;
-                        unsigned spins = 0;
-                        while (k >= known) {
-                            __builtin_amdgcn_s_sleep(2);
-                            poll();
-                            if ((++spins & 255) == 0) {
-                                if (__hip_atomic_load(abortw, RLX, AGENT)) { aborted = true; break; }
-                                if (spins > kSpinLimit) { __hip_atomic_store(abortw, 4u, RLX, AGENT); aborted = true; break; }
-                            }
-                        }
-                        if (aborted) { ps.valid = false; return true; }
-                    }
-                }
-                const int idx = __builtin_amdgcn_readfirstlane(k - k0);
-                const int cb = __builtin_amdgcn_readlane(cellwin.x, idx);
-                const int cl = __builtin_amdgcn_readlane(cellwin.y, idx);
-                const int ib = __builtin_amdgcn_readlane(itemwin, idx);
-                const int n = cw + k * CW;
-                const int j = (gi * S + n) * H + hme;
-                ++k;
-                if (cl == 0) {                       // nothing of this tile in the item (or no tile): release at once
-                    if (lane == 0) __hip_atomic_fetch_add(done + j, 1u, RLX, AGENT);
-                    continue;
-                }
-                cur_begin = cb; cur_len = cl; cur_off = 0; cur_j = j;
-                cur_ring = ((static_cast<unsigned>(team) * G + j % G) * D + (j / G) % D) * p.slot_cap + static_cast<unsigned>(cb - ib);
-            }
-        };
-        auto issue = [&](Pass& ps) {
-            const unsigned i = static_cast<unsigned>(ps.off) + 4u * lane;
-            const unsigned at = min(i, static_cast<unsigned>(ps.len - 4));
-            ps.prod = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rsrc, (ps.ringbase + at) * 4u, 0, 16));
-            ps.dw = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p.a_drow + ps.begin + at));
-        };
-        int row_base = 0;
-        auto process = [&](const Pass& ps) {
-            const unsigned i = static_cast<unsigned>(ps.off) + 4u * lane;
-            if (ps.off == 0) row_base = 0;
-            const unsigned word = i < static_cast<unsigned>(ps.len) ? ps.dw : 0xFFFFFFFFu;
-            int delta[4], upto[4], sum = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { delta[e] = (word >> (8 * e)) & 0xFF; sum += delta[e]; upto[e] = sum; }
-            const int incl = wave_inclusive_scan(sum);
-            const int lane_base = row_base + incl - sum;
-            row_base += __builtin_amdgcn_readlane(incl, 63);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                double* target = delta[e] != 255 ? &tile[lane_base + upto[e]] : &spare[lane];
-                atomicAdd(target, static_cast<double>(ps.prod[e]));
-            }
-            if (ps.last) {                           // the run's products are in registers: its slot share may be reused
-                asm volatile("" :: "v"(ps.prod[0]) : "memory");
-                if (lane == 0) __hip_atomic_fetch_add(done + ps.j, 1u, RLX, AGENT);
-            }
-        };
-        // P passes in flight per wavefront.  Pass i of the stream always sits in slot i mod P, so the round-robin
-        // visit processes the passes in stream order (a run's row base carries from pass to pass).  When the next
-        // item is not ready, nothing more is fetched; the slots in flight drain and a new EPOCH starts with slot 0
-        // waiting for that item — a wavefront never waits while it holds unprocessed (unreleased) products.
-        constexpr int P = 4;
-        Pass ps[P];
-        int state[P];                                 // 1: loads issued, 2: empty
-        for (bool ended = false; !ended && !aborted;) {
-            bool stalled = false;
-#pragma unroll
-            for (int u = 0; u < P; ++u) {
-                state[u] = 2;
-                if (stalled) continue;
-                const bool got = advance(ps[u], u == 0);
-                if (!got) { stalled = true; continue; }
-                if (!ps[u].valid) { stalled = true; ended = true; continue; }
-                issue(ps[u]);
-                state[u] = 1;
-            }
-            for (bool run = state[0] == 1; run;) {
-#pragma unroll
-                for (int u = 0; u < P; ++u) {
-                    if (state[u] != 1) { run = false; break; }
-                    process(ps[u]);
-                    state[u] = 2;
-                    if (stalled) continue;
-                    const bool got = advance(ps[u], false);
-                    if (!got) { stalled = true; continue; }
-                    if (!ps[u].valid) { stalled = true; ended = true; continue; }
-                    issue(ps[u]);
-                    state[u] = 1;
-                }
-            }
-        }
-        if (aborted) { __hip_atomic_store(&ctl[4], 1u, RLX, WG); }
-        cphase += CW;
-        if (!sub_barrier(&ctl[1], cphase, &ctl[4]) || __hip_atomic_load(&ctl[4], RLX, WG)) return;
-        for (int i = ctid; i < p.R; i += CW * 64) {
-            const long long row = static_cast<long long>(t) * p.R + i;
-            if (active && row < p.num_rows) p.y[row] = static_cast<float>(tile[i]);
-            tile[i] = 0.0;
-        }
-        cphase += CW;
-        if (!sub_barrier(&ctl[1], cphase, &ctl[4])) return;
-    }
-    if (lane == 0) atomicAdd(&p.ctl[9], polls);
-}
-
-// ------------------------------------------------------------------------------------------ split roles
 // Two 1024-thread workgroups per CU (LDS max(W * 4, R * 8) each): the first to arrive on a CU (per-CU counter keyed by
 // XCC_ID and HW_ID's SE/SH/CU fields) becomes a CONSUMER, the second a PRODUCER, so every CU's LDS pipe carries one
-// tile's adds and one strip's gathers; sixteen wavefronts per role, hardware barriers inside a role.  One team of all
-// CUs ("global"): ring written through (sc1 stores), read with sc1 loads.
-template <int P>
+// tile's adds and one strip's gathers; sixteen wavefronts per role, hardware barriers inside a role.
+// Consumer wavefront: strips cw, cw + 16, ...; a 64-item window of (run begin, length, ring offset, item id) lives one
+// item per lane; items known to be ready are walked in BATCHES by a loop that contains nothing but the P-deep software
+// pipeline (loads issued unconditionally, so the compiler's vmcnt bookkeeping stays exact); the batch's done signals go
+// out afterwards as one vector atomic.
+template <int P, int E>
 __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     __shared__ unsigned sh[4];
@@ -353,7 +100,7 @@ __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         const unsigned cu = ((xcc & 0xF) << 8) | ((hw >> 8) & 0xFF);
         const unsigned arrival = atomicAdd(&p.ctl[16 + cu], 1u);
-        const unsigned role = arrival & 1;                       // 0 consumer, 1 producer
+        const unsigned role = p.mode == 5 ? 0u : arrival & 1;    // 0 consumer, 1 producer (mode 5: every workgroup consumes)
         sh[0] = role; sh[2] = 0; sh[3] = 0;
         sh[1] = atomicAdd(&p.ctl[10 + role], 1u);                // index inside the role
     }
@@ -387,8 +134,8 @@ __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
             for (int i = ptid * 4; i < p.W; i += 1024 * 4) {
                 *reinterpret_cast<f32x4*>(xs + i) = *reinterpret_cast<const f32x4*>(src + i);
             }
-            if (wave == 0 && n >= D && p.mode == 0) {
-                if (!spin_until_ge(done + (j - G * D), consumers_per_item, abortw)) sh[2] = 1;
+            if (wave == 0 && n >= D && (p.mode == 0 || p.mode == 4)) {
+                if (!spin_until_ge(done + static_cast<size_t>(j - G * D) * kDoneStride, consumers_per_item, abortw)) sh[2] = 1;
             }
             __syncthreads();
             if (sh[2]) return;
@@ -417,9 +164,11 @@ __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) {
-                const int flag = ((gi * H + h) * CW + s % CW) * p.SC + s / CW;
-                __hip_atomic_store(ready + flag, 1u, RLX, AGENT);
+            // one flag per consumer of the item, each in that consumer's own mailbox (no line is polled by two workgroups)
+            const int flag = (gi * CW + s % CW) * p.SC + s / CW;
+            for (int cc = threadIdx.x; cc < static_cast<int>(consumers_per_item); cc += 1024) {
+                const int consumer = h * static_cast<int>(consumers_per_item) + cc;
+                __hip_atomic_store(ready + static_cast<size_t>(consumer) * p.ready_per_team + flag, 1u, RLX, AGENT);
             }
         }
         return;
@@ -434,19 +183,27 @@ __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
     __syncthreads();
     const int mine = (S - cw + CW - 1) / CW;
     unsigned polls = 0;
+    constexpr int kSpan = 64 * E;                 // slots per pass
+    constexpr int kGroups = E / 4;                // 16-byte product loads per lane and pass
+    constexpr int kBatch = 8;                     // items per batch: bounds how long a done signal waits
     for (int gi = 0; gi < p.NG; ++gi) {
         const int t = gi * G + member;
         const bool active = t < p.T;
-        const unsigned* flags = ready + ((gi * H + hme) * CW + cw) * p.SC;
-        int k0 = 0, known = p.mode == 2 ? mine : 0, k = 0;
-        int2 cellwin; int itemwin;
+        const unsigned* flags = ready + static_cast<size_t>(member) * p.ready_per_team + (gi * CW + cw) * p.SC;
+        int k0 = 0, known = (p.mode == 2 || p.mode == 3 || p.mode == 5) ? mine : 0, k = 0;
+        int wbegin = 0, wlen = 0, wj = 0; unsigned wring = 0;      // the window: lane l holds item k0 + l
         auto load_window = [&]() {
             const int kk = k0 + lane;
-            cellwin = make_int2(0, 0); itemwin = 0;
+            wbegin = 0; wlen = 0; wj = 0; wring = 0;
             if (kk < mine) {
                 const int n = cw + kk * CW;
-                if (active) cellwin = p.cells_t[static_cast<size_t>(t) * S + n];
-                itemwin = p.items[(static_cast<size_t>(gi) * S + n) * H + hme].x;
+                wj = (gi * S + n) * H + hme;
+                if (active) {
+                    const int2 cell = p.cells_t[static_cast<size_t>(t) * S + n];
+                    const int ib = p.items[(static_cast<size_t>(gi) * S + n) * H + hme].x;
+                    wbegin = cell.x; wlen = cell.y;
+                    wring = (static_cast<unsigned>(wj % G) * D + (wj / G) % D) * p.slot_cap + static_cast<unsigned>(cell.x - ib);
+                }
             }
         };
         auto poll = [&]() {
@@ -459,105 +216,87 @@ __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
             ++polls;
         };
         load_window();
-        struct Pass { bool valid, last; int begin, len, off, j; unsigned ringbase; f32x4 prod; unsigned dw; };
-        int cur_begin = 0, cur_len = 0, cur_off = 0, cur_j = 0; unsigned cur_ring = 0;
         bool aborted = false;
-        auto advance = [&](Pass& ps, bool blocking) -> bool {
-            for (;;) {
-                if (cur_off < cur_len) {
-                    ps.valid = true; ps.begin = cur_begin; ps.len = cur_len; ps.off = cur_off; ps.j = cur_j; ps.ringbase = cur_ring;
-                    cur_off += 256;
-                    ps.last = cur_off >= cur_len;
-                    return true;
-                }
-                if (k >= mine) { ps.valid = false; return true; }
-                if (k >= k0 + 64) { k0 += 64; load_window(); }
-                if (k >= known) {
+        while (k < mine && !aborted) {
+            if (k >= k0 + 64) { k0 += 64; load_window(); }
+            if (k >= known) {
+                poll();
+                unsigned spins = 0;
+                while (k >= known) {
+                    __builtin_amdgcn_s_sleep(8);
                     poll();
-                    if (k >= known) {
-                        if (!blocking) return false;
-                        unsigned spins = 0;
-                        while (k >= known) {
-                            __builtin_amdgcn_s_sleep(2);
-                            poll();
-                            if ((++spins & 255) == 0) {
-                                if (__hip_atomic_load(abortw, RLX, AGENT)) { aborted = true; break; }
-                                if (spins > kSpinLimit) { __hip_atomic_store(abortw, 4u, RLX, AGENT); aborted = true; break; }
-                            }
-                        }
-                        if (aborted) { ps.valid = false; return true; }
+                    if ((++spins & 255) == 0) {
+                        if (__hip_atomic_load(abortw, RLX, AGENT)) { aborted = true; break; }
+                        if (spins > kSpinLimit) { __hip_atomic_store(abortw, 4u, RLX, AGENT); aborted = true; break; }
                     }
                 }
-                const int idx = __builtin_amdgcn_readfirstlane(k - k0);
-                const int cb = __builtin_amdgcn_readlane(cellwin.x, idx);
-                const int cl = __builtin_amdgcn_readlane(cellwin.y, idx);
-                const int ib = __builtin_amdgcn_readlane(itemwin, idx);
-                const int n = cw + k * CW;
-                const int j = (gi * S + n) * H + hme;
-                ++k;
-                if (cl == 0) {
-                    if (lane == 0) __hip_atomic_fetch_add(done + j, 1u, RLX, AGENT);
-                    continue;
+                if (aborted) break;
+            }
+            const int kend = min(min(known, k + kBatch), k0 + 64);
+            // ---- the batch: items [k, kend) of the window, nothing but the pipeline inside
+            struct Pass { int valid, begin, len, off; unsigned ring; f32x4 prod[kGroups]; unsigned dw[kGroups]; };
+            int c = __builtin_amdgcn_readfirstlane(k - k0);
+            const int cend = __builtin_amdgcn_readfirstlane(kend - k0);
+            int off = 0;
+            auto next = [&](Pass& ps) {
+                while (c < cend && __builtin_amdgcn_readlane(wlen, c) == 0) ++c;
+                if (c < cend) {
+                    ps.valid = 1;
+                    ps.begin = __builtin_amdgcn_readlane(wbegin, c);
+                    ps.len = __builtin_amdgcn_readlane(wlen, c);
+                    ps.ring = __builtin_amdgcn_readlane(static_cast<int>(wring), c);
+                    ps.off = off;
+                    off += kSpan;
+                    if (off >= ps.len) { ++c; off = 0; }
+                } else {
+                    ps.valid = 0;                      // keeps its last geometry: the loads below re-read valid memory
                 }
-                cur_begin = cb; cur_len = cl; cur_off = 0; cur_j = j;
-                cur_ring = (static_cast<unsigned>(j % G) * D + (j / G) % D) * p.slot_cap + static_cast<unsigned>(cb - ib);
-            }
-        };
-        auto issue = [&](Pass& ps) {
-            const unsigned i = static_cast<unsigned>(ps.off) + 4u * lane;
-            const unsigned at = min(i, static_cast<unsigned>(ps.len - 4));
-            ps.prod = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rsrc, (ps.ringbase + at) * 4u, 0, 16));
-            ps.dw = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p.a_drow + ps.begin + at));
-        };
-        int row_base = 0;
-        auto process = [&](const Pass& ps) {
-            const unsigned i = static_cast<unsigned>(ps.off) + 4u * lane;
-            if (ps.off == 0) row_base = 0;
-            const unsigned word = i < static_cast<unsigned>(ps.len) ? ps.dw : 0xFFFFFFFFu;
-            int delta[4], upto[4], sum = 0;
+            };
+            auto issue = [&](Pass& ps) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { delta[e] = (word >> (8 * e)) & 0xFF; sum += delta[e]; upto[e] = sum; }
-            const int incl = wave_inclusive_scan(sum);
-            const int lane_base = row_base + incl - sum;
-            row_base += __builtin_amdgcn_readlane(incl, 63);
+                for (int g4 = 0; g4 < kGroups; ++g4) {
+                    const unsigned i = static_cast<unsigned>(ps.off) + E * lane + 4u * g4;
+                    const unsigned at = min(i, static_cast<unsigned>(ps.len - 4));
+                    ps.prod[g4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rsrc, (ps.ring + at) * 4u, 0, 16));
+                    ps.dw[g4] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p.a_drow + ps.begin + at));
+                }
+            };
+            int row_base = 0;
+            auto process = [&](const Pass& ps) {
+                if (ps.off == 0) row_base = 0;
+                int delta[E], upto[E], sum = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                double* target = delta[e] != 255 ? &tile[lane_base + upto[e]] : &spare[lane];
-                atomicAdd(target, static_cast<double>(ps.prod[e]));
-            }
-            if (ps.last) {
-                asm volatile("" :: "v"(ps.prod[0]) : "memory");
-                if (lane == 0) __hip_atomic_fetch_add(done + ps.j, 1u, RLX, AGENT);
-            }
-        };
-        Pass ps[P];
-        int state[P];
-        for (bool ended = false; !ended && !aborted;) {
-            bool stalled = false;
+                for (int g4 = 0; g4 < kGroups; ++g4) {
+                    const unsigned i = static_cast<unsigned>(ps.off) + E * lane + 4u * g4;
+                    const unsigned word = i < static_cast<unsigned>(ps.len) ? ps.dw[g4] : 0xFFFFFFFFu;
 #pragma unroll
-            for (int u = 0; u < P; ++u) {
-                state[u] = 2;
-                if (stalled) continue;
-                const bool got = advance(ps[u], u == 0);
-                if (!got) { stalled = true; continue; }
-                if (!ps[u].valid) { stalled = true; ended = true; continue; }
-                issue(ps[u]);
-                state[u] = 1;
-            }
-            for (bool run = state[0] == 1; run;) {
+                    for (int e = 0; e < 4; ++e) { delta[4 * g4 + e] = (word >> (8 * e)) & 0xFF; sum += delta[4 * g4 + e]; upto[4 * g4 + e] = sum; }
+                }
+                const int incl = wave_inclusive_scan(sum);
+                const int lane_base = row_base + incl - sum;
+                row_base += __builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    double* target = delta[e] != 255 ? &tile[lane_base + upto[e]] : &spare[lane];
+                    atomicAdd(target, static_cast<double>(ps.prod[e / 4][e % 4]));
+                }
+            };
+            Pass ps[P];
+#pragma unroll
+            for (int u = 0; u < P; ++u) { ps[u].begin = 0; ps[u].len = 4; ps[u].off = 0; ps[u].ring = 0; next(ps[u]); issue(ps[u]); }
+            for (bool more = true; more;) {
 #pragma unroll
                 for (int u = 0; u < P; ++u) {
-                    if (state[u] != 1) { run = false; break; }
+                    if (!ps[u].valid) { more = false; break; }
                     process(ps[u]);
-                    state[u] = 2;
-                    if (stalled) continue;
-                    const bool got = advance(ps[u], false);
-                    if (!got) { stalled = true; continue; }
-                    if (!ps[u].valid) { stalled = true; ended = true; continue; }
+                    next(ps[u]);
                     issue(ps[u]);
-                    state[u] = 1;
                 }
             }
+            asm volatile("" ::: "memory");
+            // every run of the batch is in registers or already added: release the slots
+            if (lane >= k - k0 && lane < kend - k0) __hip_atomic_fetch_add(done + static_cast<size_t>(wj) * kDoneStride, 1u, RLX, AGENT);
+            k = kend;
         }
         if (aborted) sh[3] = 1;
         __syncthreads();
@@ -618,14 +357,13 @@ __global__ void compare(const float* y, const double* yref, long long n, unsigne
 }
 
 int main(int argc, char** argv) {
-    // fused_bench <local|global> W R D H PW [L] [reps]
-    const bool local = argc > 1 ? strcmp(argv[1], "local") == 0 : true;
-    const bool split = argc > 1 && strcmp(argv[1], "split") == 0;        // two workgroups per CU, one per role; PW = passes in flight
-    const int W = argc > 2 ? atoi(argv[2]) : 16384;
-    const int R = argc > 3 ? atoi(argv[3]) : 9792;
-    const int D = argc > 4 ? atoi(argv[4]) : 2;
-    const int H = argc > 5 ? atoi(argv[5]) : 1;
-    const int PW = argc > 6 ? atoi(argv[6]) : 8;
+    // fused_bench W R D H P E [reps] [mode]
+    const int W = argc > 1 ? atoi(argv[1]) : 16384;
+    const int R = argc > 2 ? atoi(argv[2]) : 9792;
+    const int D = argc > 3 ? atoi(argv[3]) : 2;
+    const int H = argc > 4 ? atoi(argv[4]) : 1;
+    const int P = argc > 5 ? atoi(argv[5]) : 3;
+    const int E = argc > 6 ? atoi(argv[6]) : 4;
     const int reps = argc > 7 ? atoi(argv[7]) : 5;
     const int mode = argc > 8 ? atoi(argv[8]) : 0;
     const long long rows = 10000000, cols = 10000000, entries = 160000000;
@@ -633,10 +371,10 @@ int main(int argc, char** argv) {
     const int L = (int)(entries / ((long long)S * T));         // mean run length
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
-    const int NT = local ? 8 : 1, G = cus / NT;
+    const int NT = 1, G = (argc > 8 && atoi(argv[8]) == 5) ? 2 * cus : cus;   // mode 5: phase 2 alone, two tiles per CU
     if (G % H) { printf("G %% H != 0\n"); return 1; }
     const int NG = (T + G - 1) / G, gpt = (NG + NT - 1) / NT;
-    const int CW = split ? 16 : 16 - PW;
+    const int CW = 16;
     const int SC = (S + CW - 1) / CW;
 
     // cells: strip-major, lengths multiples of 4 around L
@@ -662,10 +400,10 @@ int main(int argc, char** argv) {
     slot_cap = (slot_cap + 63) / 64 * 64;
     const size_t ring_floats = (size_t)NT * G * D * slot_cap;
     if (ring_floats * 4 >= (1ull << 32)) { printf("ring too large\n"); return 1; }
-    const int items_per_team = gpt * S * H, ready_per_team = gpt * H * CW * SC;
+    const int items_per_team = gpt * S * H, ready_per_team = (gpt * CW * SC + 63) / 64 * 64;     // ready: one mailbox per consumer
 
-    printf("%s  W %d R %d  S %d T %d  run %d  G %d H %d D %d  groups %d (%d per team)  PW %d CW %d  slots %lld  item <= %u slots  ring %.1f MB  LDS %d B\n",
-           split ? "split " : local ? "local " : "global", W, R, S, T, L, G, H, D, NG, gpt, PW, CW, total, slot_cap, ring_floats * 4 / 1048576.0, W * 4 + R * 8 + 512 + 64);
+    printf("W %d R %d  S %d T %d  run %d  G %d H %d D %d  groups %d  P %d E %d  slots %lld  item <= %u slots  ring %.1f MB  LDS %zu B\n",
+           W, R, S, T, L, G, H, D, NG, P, E, total, slot_cap, ring_floats * 4 / 1048576.0, std::max((size_t)W * 4, (size_t)R * 8));
     fflush(stdout);
 
     float *a_val, *x, *y, *ring; unsigned short* a_lcol; unsigned char* a_drow; int *d_begin, *d_len; int2 *d_cells_t, *d_items;
@@ -675,7 +413,7 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&ring, ring_floats * 4)); CHECK(hipMalloc(&d_begin, (cells + 1) * 4)); CHECK(hipMalloc(&d_len, cells * 4));
     CHECK(hipMalloc(&d_cells_t, cells_t.size() * 8)); CHECK(hipMalloc(&d_items, items.size() * 8));
     const size_t ctl_words = 16 + 4096;                      // registration, abort, statistics; per-CU arrival counters
-    const size_t flag_words = ctl_words + (size_t)NT * (items_per_team + ready_per_team);
+    const size_t flag_words = ctl_words + (size_t)items_per_team * kDoneStride + (size_t)G * ready_per_team;
     CHECK(hipMalloc(&flags, flag_words * 4)); CHECK(hipMalloc(&bad, 8));
     CHECK(hipMemcpy(d_begin, begin.data(), (cells + 1) * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_len, len.data(), cells * 4, hipMemcpyHostToDevice));
@@ -691,24 +429,20 @@ int main(int argc, char** argv) {
     p.S = S; p.T = T; p.R = R; p.W = W; p.G = G; p.H = H; p.D = D; p.NT = NT; p.NG = NG; p.gpt = gpt;
     p.num_rows = (int)rows; p.SC = SC; p.slot_cap = slot_cap; p.ring_bytes = (unsigned)(ring_floats * 4);
     p.a_val = a_val; p.a_lcol = a_lcol; p.a_drow = a_drow; p.cells_t = d_cells_t; p.items = d_items; p.x = x; p.y = y; p.ring = ring;
-    p.ctl = flags; p.done = flags + ctl_words; p.ready = flags + ctl_words + (size_t)NT * items_per_team;
+    p.ctl = flags; p.done = flags + ctl_words; p.ready = flags + ctl_words + (size_t)items_per_team * kDoneStride;
     p.items_per_team = items_per_team; p.ready_per_team = ready_per_team; p.mode = 0;
-    const size_t lds = split ? std::max((size_t)W * 4, (size_t)R * 8) : (size_t)W * 4 + (size_t)R * 8 + 512 + 64;
+    const size_t lds = std::max((size_t)W * 4, (size_t)R * 8);
 
     auto launch = [&]() {
         CHECK(hipMemsetAsync(flags, 0, flag_words * 4, 0));
-#define GO(PWV, LOC) do { auto kern = fused<PWV, 16 - PWV, LOC>; \
-        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        kern<<<cus, 1024, lds, 0>>>(p); } while (0)
-        if (split) {
-#define GOS(PV) do { auto kern = fused_split<PV>; \
+#define GOS(PV, EV) do { auto kern = fused_split<PV, EV>; \
         CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         kern<<<2 * cus, 1024, lds, 0>>>(p); } while (0)
-            if (PW == 1) GOS(1); else if (PW == 2) GOS(2); else if (PW == 3) GOS(3); else GOS(4);
-        } else if (local) { if (PW == 8) GO(8, true); else if (PW == 6) GO(6, true); else if (PW == 4) GO(4, true); else GO(10, true); }
-        else       { if (PW == 8) GO(8, false); else if (PW == 6) GO(6, false); else if (PW == 4) GO(4, false); else GO(10, false); }
+        if (E == 8) { if (P == 2) GOS(2, 8); else if (P == 3) GOS(3, 8); else GOS(4, 8); }
+        else        { if (P == 2) GOS(2, 4); else if (P == 3) GOS(3, 4); else if (P == 4) GOS(4, 4); else GOS(6, 4); }
         CHECK(hipGetLastError());
     };
+    if (mode == 5) p.mode = 5;                 // the checked run needs both roles at G = CUs: not available in this shape
     CHECK(hipMemset(y, 0xFF, (size_t)T * R * 4));
     launch();
     CHECK(hipDeviceSynchronize());
@@ -725,7 +459,7 @@ int main(int argc, char** argv) {
     fflush(stdout);
 
     p.mode = mode;
-    if (mode) printf("PROBE mode %d (%s only): results are not checked\n", mode, mode == 1 ? "producers" : "consumers");
+    if (mode) printf("PROBE mode %d (%s): results are not checked\n", mode, mode == 1 ? "producers only" : mode == 2 ? "consumers only" : mode == 5 ? "phase 2 alone: two consumer workgroups per CU, products from a ring far larger than the caches" : "both roles, no flow control");
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     float best = 1e9f, sum = 0;
     for (int r = 0; r < reps; ++r) {
@@ -741,6 +475,6 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(&bad_host, bad, 8, hipMemcpyDeviceToHost));
     const double alg = 1.400000004e9;
     printf("fused step (memset + kernel): avg %.1f us  best %.1f us  => %.3f of 8 TB/s on 1.40 GB algorithmic | polls per consumer wave %.1f | abort %u | bad rows after timing %llu\n",
-           sum / reps * 1e3, best * 1e3, alg / (best * 1e-3) / 8e12, ctl_host[9] / (double)(cus * CW), ctl_host[8], bad_host);
+           sum / reps * 1e3, best * 1e3, alg / (best * 1e-3) / 8e12, ctl_host[9] / (double)(cus * 16), ctl_host[8], bad_host);
     return 0;
 }

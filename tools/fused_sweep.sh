@@ -5,13 +5,11 @@ out=gpurun_out/fused_bench.txt
 mkdir -p gpurun_out
 : > $out
 run() { echo "== $*" >> $out; timeout -k 10 90 tools/fused_bench "$@" >> $out 2>&1 || { echo "FAILED rc=$? : $*" >> $out; return 1; }; }
-# <local|global|split> W R D H PW|P reps mode
-run split 16384 9792 2 1 2 5 0 &&
-run split 16384 9792 2 1 2 5 1 &&
-run split 16384 9792 2 1 2 5 2 &&
-run split 16384 9792 2 1 4 5 0 &&
-run split 16384 9792 2 1 4 5 2 &&
-run split 16384 9792 2 2 2 5 0 &&
-run split 16384 9792 3 2 2 5 0 &&
-run split 16384 9792 3 4 2 5 0
-grep -v "^rows diff" $out
+# W R D H P E reps mode
+run 16384 9792 2 1 2 4 5 5 &&
+run 16384 9792 2 1 3 4 5 5 &&
+run 16384 9792 2 1 4 4 5 5 &&
+run 16384 9792 2 1 6 4 5 5 &&
+run 16384 9792 2 1 3 8 5 5 &&
+run 16384 9792 2 1 4 8 5 5 
+grep -v "^rows diff\|^registration" $out

@@ -55,8 +55,103 @@ def csr_bytes(rows, cols, nnz):
     return nnz * 8 + (rows + 1) * 4 + cols * 4 + rows * 4
 
 
+
+# ------------------------------------------------------------------------------------------------
+# One JSON line, whatever happens after the measurement.
+#
+# The measurement itself (W + K steps of the one-collective loop, then the step kernel under HIP events)
+# comes first.  Everything after it — CPU baseline, spmv_csr table, parity report, folded plan, opt-in exchange
+# trials — can only ADD keys.  By default bench.py runs as a SUPERVISOR that never touches the GPU: it starts
+# the real run as a child (same interpreter, same arguments, SPMV_BENCH_CHILD=1) and reads the child's
+# stdout.  The child writes a complete line as soon as the measurement stands and again after every extra;
+# the supervisor prints the LAST line it received when the child ends — normally, by a Python exception, by
+# a GPU fault that aborts the process, by a signal, or by the deadline for the extras (a hung collective) —
+# and exits 0 once a measured line exists.  Under a profiler (rocprofv3 preloads a library that has
+# already initialised the GPU, so this process must not start another program) or with
+# SPMV_BENCH_INPROCESS=1 the run stays in this process and prints its line from a `finally`.
+def _under_profiler():
+    preload = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in preload or any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ)
+
+
+def supervise(child_cmd=None):
+    import signal
+    import subprocess
+    import threading
+
+    rank = int(os.environ.get("RANK", "0"))
+    env = dict(os.environ, SPMV_BENCH_CHILD="1")
+    child = subprocess.Popen(child_cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                             stdout=subprocess.PIPE, env=env, start_new_session=True)
+    state = {"line": None, "measured_at": None, "final": False}
+
+    def reader():
+        for raw in child.stdout:
+            text = raw.decode(errors="replace").strip()
+            if text == "MEASURED":                       # ranks other than 0: the timed region is over
+                state["measured_at"] = time.time()
+                continue
+            try:
+                obj = json.loads(text)
+            except ValueError:
+                print(text, file=sys.stderr, flush=True)  # a library wrote to the child's stdout: not ours
+                continue
+            state["line"] = obj
+            state["final"] = not obj.get("provisional", False)
+            if state["measured_at"] is None:
+                state["measured_at"] = time.time()
+
+    thread = threading.Thread(target=reader, daemon=True)
+    thread.start()
+
+    def finish(reason):
+        if child.poll() is None:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except OSError:
+                pass
+        thread.join(timeout=5)
+        obj = state["line"]
+        if obj is not None and rank == 0:
+            if obj.pop("provisional", False) or reason:
+                obj["incomplete"] = reason or "the run ended before its last extra (exit code %s)" % child.returncode
+            sys.stdout.write(json.dumps(obj) + "\n")
+            sys.stdout.flush()
+        measured = state["measured_at"] is not None
+        rc = child.returncode if child.returncode is not None else -9
+        os._exit(0 if measured else (rc if rc > 0 else 1))
+
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, lambda number, frame: finish("signal %d while the extras were running" % number))
+    deadline = float(os.environ.get("SPMV_BENCH_EXTRAS_DEADLINE", "1500"))
+    while child.poll() is None:
+        time.sleep(0.2)
+        if state["measured_at"] is not None and not state["final"] and time.time() - state["measured_at"] > deadline:
+            finish("the extras did not finish within %.0f s of the measurement: child killed" % deadline)
+    finish(None)
+
+
+def _fail_here(stage):
+    """Test hook: SPMV_BENCH_FAIL_IN=<stage>:<raise|abort|hang> breaks the named stage on purpose."""
+    spec = os.environ.get("SPMV_BENCH_FAIL_IN", "")
+    if not spec:
+        return
+    name, _, how = spec.partition(":")
+    if name != stage:
+        return
+    if how == "abort":
+        os.abort()
+    if how == "hang":
+        while True:
+            time.sleep(1)
+    raise RuntimeError("SPMV_BENCH_FAIL_IN asked stage %r to fail" % stage)
+
+
 def main():
     args = parse()
+    if os.environ.get("SPMV_BENCH_CHILD") != "1" and os.environ.get("SPMV_BENCH_INPROCESS", "0") != "1" \
+            and not _under_profiler():
+        supervise()                                   # never returns
     # The contract: stdout carries exactly ONE line, the JSON.  Libraries write there too (RCCL prints a version
     # banner on stdout when a communicator is created), so file descriptor 1 is pointed at stderr for the run and
     # the line goes out through a private duplicate of the real stdout.
@@ -174,70 +269,8 @@ def main():
         return seconds
 
     elapsed = timed(pr, engine)
-    exchange_trials = None
-
-    # ---- N > 1: the same K steps with the OVERLAPPED exchange (Layout(chunks=C): C all-gathers per step, the
-    # products of block c computed while block c + 1 is on the links; pagerank_dist.py).  Same collectives, same
-    # kernels, another numbering of the vector — so it is first checked against the one-collective run (4 steps
-    # from the start vector, every node within 1e-5 relative on every rank), and the recorded number is whichever
-    # form was fastest over the same W + K steps; config.exchange says which.  SPMV_PR_OVERLAP=0 skips it,
-    # SPMV_PR_OVERLAP=<C>[,<C>...] sets the block counts to try (default 4,2).
-    candidates = [int(c) for c in os.environ.get("SPMV_PR_OVERLAP", "4,2").split(",") if c.strip()]
-    candidates = [c for c in candidates if c > 1]
-    if layout.exchange and candidates:
-        def after(loop, steps):
-            loop.reset()
-            for i in range(steps):
-                loop.iterate(i, damping, never)
-            torch.cuda.synchronize()
-            return loop.r[steps & 1][loop._pos].clone()
-        ref = after(pr, 4)
-        exchange_trials = {"gather_ms_per_step": round(elapsed / args.steps * 1e3, 4), "overlapped": []}
-        best = (elapsed, engine, pr, layout, cols_v, exchange)
-        # Whatever goes wrong in a trial (the same Python exception on every rank — a rank-dependent failure cannot be
-        # caught from here) costs the trial, not the result line: the one-collective measurement above stands.
-        try:
-            for blocks in candidates:
-                lay2 = prd.Layout(n, world, rank, chunks=blocks, exchange=True)
-                cols2 = torch.empty_like(cols)
-                scratch_ptrs, scratch_vals = torch.empty_like(row_ptrs), torch.empty_like(vals)
-                status = spmv.lib().spmv_c_gen_uniform_rows(args.seed, row_begin, local_rows, n, k, scratch_ptrs.data_ptr(),
-                                                            cols2.data_ptr(), scratch_vals.data_ptr(), stream)   # the node ids again
-                assert status == 0, spmv.spmv_error_string(status)
-                torch.cuda.synchronize()
-                del scratch_ptrs, scratch_vals
-                cols2_v = cols2[: local_rows * k]
-                cols2_v.copy_(lay2.remap_columns(cols2_v))
-                # (its own copy of the row pointers: the library keys a matrix's cached plan by that array)
-                engine2 = prd.HipEngine(row_ptrs.clone(), cols2_v, vals_v, lay2)
-                pr2 = prd.ShardedPageRank(engine2, lay2).prepare()
-                got = after(pr2, 4)
-                worst = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max())
-                agree = torch.tensor([1 if worst <= 1e-5 else 0], dtype=torch.int32, device=device)
-                dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-                del got
-                trial = {"blocks": blocks, "max_rel_diff_after_4_steps": worst, "agrees": bool(int(agree.item()))}
-                keep = False
-                if trial["agrees"]:
-                    elapsed2 = timed(pr2, engine2)
-                    trial["ms_per_step"] = round(elapsed2 / args.steps * 1e3, 4)
-                    keep = elapsed2 < best[0]           # the same verdict on every rank (all-reduced maxima)
-                exchange_trials["overlapped"].append(trial)
-                if keep:
-                    if best[1] is not engine:           # the plain loop stays until the end (it made `ref`)
-                        best[1].close()
-                        best[2].close()
-                    best = (elapsed2, engine2, pr2, lay2, cols2_v, "gather-overlapped x%d" % blocks)
-                else:
-                    engine2.close()
-                    pr2.close()
-        except Exception as exc:                                    # noqa: BLE001
-            exchange_trials["aborted"] = repr(exc)
-        del ref
-        if best[1] is not engine:
-            engine.close()
-            pr.close()
-        elapsed, engine, pr, layout, cols_v, exchange = best
+    if rank != 0 and os.environ.get("SPMV_BENCH_CHILD") == "1":
+        os.write(result_fd, b"MEASURED\n")          # tells this rank's supervisor that the timed region is over
 
     bytes_per_step = csr_bytes(n, n, nnz_total)
     ms_per_step = elapsed / args.steps * 1e3
@@ -276,9 +309,19 @@ def main():
     step_kernels = ("tiled_expand_kernel + tiled_pagerank_reduce_kernel (two launches per step: bucketed-slot "
                     "propagation-blocking engine, x strips and y tiles in LDS)"
                     if tiled else "pr_step_kernel (fused vector-CSR direct-gather SpMV + PageRank update)")
+    # what the bound is: `frac` prices the ALGORITHMIC bytes; the engine moves `traffic` bytes
+    # (1.84x of them: the product round trip), and that traffic over the same time is what the memory system
+    # actually carried — a kernel saturated on wasted bytes, not an idle one
+    traffic_frac = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None
     roofline = {"bound": "hbm", "kernel": step_kernels,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_frac": traffic_frac,
+                "floor_note": ("frac = algorithmic bytes / kernel time / peak; traffic_frac = the bytes the kernels really moved "
+                               "(PMC) over the same time: the two-phase engine streams 15 B per entry (7 B of bucketed matrix + "
+                               "a 4 B product written and read back) against the byte model's 8 B, at the rate the L2-miss path "
+                               "sustains for that read/write mix (profiles/r02_mall_bench.txt, r03_fused_bench.txt)")
+                              if tiled else None,
                 "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": local_bytes,
                 "tiled_plan": plan_info}
 
@@ -300,7 +343,10 @@ def main():
                    "parallelism": "row-shard x%d%s" % (world, "" if world == 1 else
                        " + %d RCCL all-gather(s) per step (%d f32/rank each, partial sums in the slice tails)"
                        % (layout.chunks, layout.piece)),
-                   "exchange": exchange, "exchange_trials": exchange_trials,
+                   "exchange": exchange,
+                   "exchange_note": None if world == 1 else
+                       "one RCCL all-gather per step (the recorded default); the overlapped and push exchanges are opt-in "
+                       "(SPMV_PR_OVERLAP / SPMV_PR_EXCHANGE), run after this line and report on stderr",
                    "values_folded": bool(plan_info and plan_info.get("values_folded"))},
         "gflops": round(2.0 * nnz_total * args.steps / elapsed / 1e9, 1),
         "pagerank_iters_per_sec": round(args.steps / elapsed, 2),
@@ -308,71 +354,172 @@ def main():
         "roofline": roofline,
     }
 
-    if rank == 0 and world == 1 and not args.no_extras:
-        # the drop-in pagerank() call end to end on the same matrix (d = 0.85, tol = 1e-6, <= 100 iterations), with
-        # the tiled plan the step engine built above already cached: first call of the process (allocates the
-        # workspace kept with the matrix and the pinned result array) and a warm one
-        calls = []
-        for _ in range(2):
-            t0 = time.perf_counter()
-            full = spmv.pagerank(engine._A, spmv.PageRankConfig(0.85, 1e-6, 100))
-            calls.append(time.perf_counter() - t0)
-            rank_sum = float(full.ranks.sum(dtype=np.float64))
-            iterations, converged, residual = full.iterations, bool(full.converged), full.final_residual
-            del full                                   # hands the pinned result array back to the pool
-        result["pagerank_api"] = {"iterations": iterations, "converged": converged, "final_residual": residual,
-                                  "seconds_total": round(calls[1], 5), "seconds_first_call": round(calls[0], 5),
-                                  "ms_per_iteration_incl_setup": round(calls[1] / max(iterations, 1) * 1e3, 3),
-                                  "rank_sum": rank_sum,
-                                  "note": "seconds_total = a call with plan and workspace warm, result delivered in the "
-                                          "library's pinned array; seconds_first_call also allocates them"}
-        result["spmv_csr_api"] = api_table(spmv, wl, engine, n, k, args.seed)
-        result["parity_report"] = parity_report(spmv, wl, args.seed)
-        result["cpu_baseline"], result["cpu_baseline_all_cores"] = cpu_baseline(spmv, row_ptrs, cols_v, vals_v, n, nnz_total)
-    elif rank == 0:
-        result["cpu_baseline"] = None
+    child = os.environ.get("SPMV_BENCH_CHILD") == "1"
+    printed = {"final": False}
 
-    if rank == 0 and world == 1 and not args.no_extras and not result["config"]["values_folded"]:
-        # the same step with the values folded into column weights (what this column-stochastic matrix
-        # allows): a second plan over the same device arrays, built with folding on
-        engine.close()
-        os.environ["SPMV_TILED_FOLD"] = "1"
-        folded = prd.HipEngine(row_ptrs, cols_v, vals_v, layout)
-        pr_f = prd.ShardedPageRank(folded, layout).prepare()
-        pr_f.reset()
-        for i in range(3):
-            pr_f.iterate(i, damping, never)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(3, 3 + args.steps):
-            pr_f.iterate(i, damping, never)
-        torch.cuda.synchronize()
-        t_f = (time.perf_counter() - t0) / args.steps
-        info_f = spmv.csr_tiled_info(folded._A)
-        folded_traffic = None
-        try:
-            folded_traffic = json.load(open(pmc_file)).get("folded", {}).get("bytes_per_step")
-        except Exception:
-            pass
-        result["pagerank_step_values_folded"] = {
-            "ms_per_step": round(t_f * 1e3, 4), "effective_gb_s": round(bytes_per_step / t_f / 1e9, 1),
-            "frac_of_hbm_peak": round(bytes_per_step / t_f / 1e9 / HBM_PEAK_GBS, 4),
-            "values_folded": bool(info_f and info_f.get("values_folded")),
-            "traffic": folded_traffic,
-            "note": "same matrix, same arithmetic (w_j * x_j rounded once per column); applies only when every "
-                    "stored entry of a column is bit-identical"}
-        folded.close()
-        pr_f.close()
-
-    if rank == 0:
+    def emit(final):
+        """The line as it stands.  Child: after the measurement and after every extra (the supervisor keeps the last one).
+        In-process: once, at the end or from the `finally` below."""
+        if rank != 0 or printed["final"]:
+            return
+        if not final and not child:
+            return
+        line = dict(result)
+        if not final:
+            line["provisional"] = True
         sys.stdout.flush()
-        os.write(result_fd, (json.dumps(result) + "\n").encode())    # before teardown: the line is out whatever happens next
-    if world > 1 and os.environ.get("SPMV_PR_EXCHANGE", "gather") in ("push", "auto"):
-        push_trial(pr, dist, torch, device, world, rank, backend, damping, never, barrier, ms_per_step)
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
+        printed["final"] = final
+
+    def extra(name, fn):
+        """An extra can add keys; a Python exception in it costs that extra only."""
+        try:
+            _fail_here(name)
+            fn()
+        except Exception as exc:                                    # noqa: BLE001
+            result.setdefault("extras_failed", {})[name] = repr(exc)
+        emit(False)
+
+    try:
+        emit(False)                                   # the measurement stands from here on
+        if rank == 0 and world == 1 and not args.no_extras:
+            def do_cpu_baseline():
+                result["cpu_baseline"], result["cpu_baseline_all_cores"] = cpu_baseline(spmv, row_ptrs, cols_v, vals_v, n, nnz_total)
+
+            def do_pagerank_api():
+                # the drop-in pagerank() call end to end on the same matrix (d = 0.85, tol = 1e-6, <= 100 iterations), with
+                # the tiled plan the step engine built above already cached: first call of the process (allocates the
+                # workspace kept with the matrix and the pinned result array) and a warm one
+                calls = []
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    full = spmv.pagerank(engine._A, spmv.PageRankConfig(0.85, 1e-6, 100))
+                    calls.append(time.perf_counter() - t0)
+                    rank_sum = float(full.ranks.sum(dtype=np.float64))
+                    iterations, converged, residual = full.iterations, bool(full.converged), full.final_residual
+                    del full                                   # hands the pinned result array back to the pool
+                result["pagerank_api"] = {"iterations": iterations, "converged": converged, "final_residual": residual,
+                                          "seconds_total": round(calls[1], 5), "seconds_first_call": round(calls[0], 5),
+                                          "ms_per_iteration_incl_setup": round(calls[1] / max(iterations, 1) * 1e3, 3),
+                                          "rank_sum": rank_sum,
+                                          "note": "seconds_total = a call with plan and workspace warm, result delivered in the "
+                                                  "library's pinned array; seconds_first_call also allocates them"}
+
+            def do_api_table():
+                result["spmv_csr_api"] = api_table(spmv, wl, engine, n, k, args.seed)
+
+            def do_parity_report():
+                result["parity_report"] = parity_report(spmv, wl, args.seed)
+
+            def do_folded():
+                # the same step with the values folded into column weights (what this column-stochastic matrix
+                # allows): a second plan over the same device arrays, built with folding on
+                if result["config"]["values_folded"]:
+                    return
+                os.environ["SPMV_TILED_FOLD"] = "1"
+                folded = prd.HipEngine(row_ptrs.clone(), cols_v, vals_v, layout)
+                pr_f = prd.ShardedPageRank(folded, layout).prepare()
+                pr_f.reset()
+                for i in range(3):
+                    pr_f.iterate(i, damping, never)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(3, 3 + args.steps):
+                    pr_f.iterate(i, damping, never)
+                torch.cuda.synchronize()
+                t_f = (time.perf_counter() - t0) / args.steps
+                info_f = spmv.csr_tiled_info(folded._A)
+                folded_traffic = None
+                try:
+                    folded_traffic = json.load(open(pmc_file)).get("folded", {}).get("bytes_per_step")
+                except Exception:
+                    pass
+                result["pagerank_step_values_folded"] = {
+                    "ms_per_step": round(t_f * 1e3, 4), "effective_gb_s": round(bytes_per_step / t_f / 1e9, 1),
+                    "frac_of_hbm_peak": round(bytes_per_step / t_f / 1e9 / HBM_PEAK_GBS, 4),
+                    "values_folded": bool(info_f and info_f.get("values_folded")),
+                    "traffic": folded_traffic,
+                    "note": "same matrix, same arithmetic (w_j * x_j rounded once per column); applies only when every "
+                            "stored entry of a column is bit-identical"}
+                folded.close()
+                pr_f.close()
+
+            result["cpu_baseline"] = None
+            extra("cpu_baseline", do_cpu_baseline)     # the contract's other object: first, and it touches no kernel
+            extra("pagerank_api", do_pagerank_api)
+            extra("spmv_csr_api", do_api_table)
+            extra("parity_report", do_parity_report)
+            extra("values_folded", do_folded)
+        elif rank == 0:
+            result["cpu_baseline"] = None
+        emit(True)
+
+        # ---- N > 1, opt-in, AFTER the line: other exchanges against the recorded all-gather.  Whatever happens in
+        # here — an exception, a fault, a hung collective on hardware these paths have never seen — the line is out.
+        overlap = [int(c) for c in os.environ.get("SPMV_PR_OVERLAP", "").split(",") if c.strip()]
+        overlap = [c for c in overlap if c > 1]
+        if layout.exchange and overlap:
+            _fail_here("trial")
+            overlap_trial(spmv, prd, dist, torch, device, args, layout, pr, engine, row_ptrs, cols, vals, vals_v, stream,
+                          damping, never, timed, elapsed, overlap)
+        if world > 1 and os.environ.get("SPMV_PR_EXCHANGE", "gather") in ("push", "auto"):
+            push_trial(pr, dist, torch, device, world, rank, backend, damping, never, barrier, ms_per_step)
+    finally:
+        emit(True)
     engine.close()
     pr.close()          # unmaps peers, barriers, then frees the rank vectors
     if world > 1 or force_exchange:
         dist.destroy_process_group()
+
+
+def overlap_trial(spmv, prd, dist, torch, device, args, layout, pr, engine, row_ptrs, cols, vals, vals_v, stream,
+                  damping, never, timed, gather_seconds, candidates):
+    """Opt-in (SPMV_PR_OVERLAP=<C>[,<C>...]), after the result line: the same K steps with the OVERLAPPED exchange
+    (Layout(chunks=C): C all-gathers per step, the products of block c computed while block c + 1 is on the links;
+    pagerank_dist.py).  Same collectives, same kernels, another numbering of the vector — so each form is first
+    checked against the one-collective run (4 steps from the start vector, every node within 1e-5 relative on every
+    rank) and then timed over the same W + K steps.  Reports on stderr."""
+    n, k, world, rank = layout.n, args.nnz_per_row, layout.world, layout.rank
+    row_begin, local_rows = layout.row_begin, layout.local_rows
+
+    def after(loop, steps):
+        loop.reset()
+        for i in range(steps):
+            loop.iterate(i, damping, never)
+        torch.cuda.synchronize()
+        return loop.r[steps & 1][loop._pos].clone()
+
+    ref = after(pr, 4)
+    report = {"gather_ms_per_step": round(gather_seconds / args.steps * 1e3, 4), "overlapped": []}
+    try:
+        for blocks in candidates:
+            lay2 = prd.Layout(n, world, rank, chunks=blocks, exchange=True)
+            cols2 = torch.empty_like(cols)
+            scratch_ptrs, scratch_vals = torch.empty_like(row_ptrs), torch.empty_like(vals)
+            status = spmv.lib().spmv_c_gen_uniform_rows(args.seed, row_begin, local_rows, n, k, scratch_ptrs.data_ptr(),
+                                                        cols2.data_ptr(), scratch_vals.data_ptr(), stream)   # the node ids again
+            assert status == 0, spmv.spmv_error_string(status)
+            torch.cuda.synchronize()
+            del scratch_ptrs, scratch_vals
+            cols2_v = cols2[: local_rows * k]
+            cols2_v.copy_(lay2.remap_columns(cols2_v))
+            # (its own copy of the row pointers: the library keys a matrix's cached plan by that array)
+            engine2 = prd.HipEngine(row_ptrs.clone(), cols2_v, vals_v, lay2)
+            pr2 = prd.ShardedPageRank(engine2, lay2).prepare()
+            got = after(pr2, 4)
+            worst = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max())
+            agree = torch.tensor([1 if worst <= 1e-5 else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            trial = {"blocks": blocks, "max_rel_diff_after_4_steps": worst, "agrees": bool(int(agree.item()))}
+            if trial["agrees"]:
+                trial["ms_per_step"] = round(timed(pr2, engine2) / args.steps * 1e3, 4)
+            report["overlapped"].append(trial)
+            engine2.close()
+            pr2.close()
+    except Exception as exc:                                    # noqa: BLE001
+        report["aborted"] = repr(exc)
+    if rank == 0:
+        print(json.dumps({"exchange_trials": report}), file=sys.stderr, flush=True)
 
 
 def push_trial(pr, dist, torch, device, world, rank, backend, damping, never, barrier, gather_ms):

@@ -34,6 +34,12 @@ struct PrWorkspace {
     float* r[2] = {nullptr, nullptr};     // the two rank vectors
     unsigned char* mask = nullptr;        // dangling mask
     bool mask_valid = false;
+    // the matrix the mask was computed for: two matrices may share one row-pointer array (every k-per-row
+    // graph has the same one), and a handle's column / value arrays may be swapped under it
+    const void* mask_cols = nullptr;
+    const void* mask_vals = nullptr;
+    long long mask_nnz = 0;
+    int mask_rows = 0, mask_num_cols = 0;
     unsigned long long num_dangling = 0;
     double* partials = nullptr;           // block partial sums / normalisation scratch
     size_t partial_count = 0;
@@ -41,7 +47,7 @@ struct PrWorkspace {
     void* state = nullptr;                // PrState on the device
     unsigned long long* dangling_count = nullptr;
     void* pinned_state = nullptr;         // PrState[2], pinned host
-    float* pinned_ranks = nullptr;        // [len] pinned host staging for the copy out
+    float* pinned_ranks = nullptr;        // [len] pinned host staging for the copy out: allocated by the first call that needs it
     hipEvent_t seen[2] = {nullptr, nullptr};
     bool busy = false;                    // a call is using it (a concurrent call on the same matrix allocates its own)
     void release();

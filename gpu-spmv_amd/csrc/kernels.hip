@@ -576,6 +576,7 @@ hipError_t prepare_csr_merge(const CSRMatrix* A, CsrAux* aux, hipStream_t s) {
     return prepare_csr_merge_locked(A, aux, s);
 }
 
+constexpr size_t kMaxExtraCarry = 7;      // streams (beyond the first) that keep a carry pair with the matrix
 hipError_t launch_csr_merge(const CSRMatrix* A, CsrAux* aux, const float* d_x, float* d_y,
                             hipStream_t s) {
     const long long total = static_cast<long long>(A->num_rows) + A->nnz;
@@ -603,7 +604,7 @@ hipError_t launch_csr_merge(const CSRMatrix* A, CsrAux* aux, const float* d_x, f
                 carry_val = c.val;
             }
         }
-        if (!carry_row) {
+        if (!carry_row && aux->extra_carry.size() < kMaxExtraCarry) {
             CsrAux::MergeCarry fresh{s, nullptr, nullptr};
             if (malloc_any_time(reinterpret_cast<void**>(&fresh.row), num_tiles * sizeof(int)) != hipSuccess ||
                 malloc_any_time(reinterpret_cast<void**>(&fresh.val), num_tiles * sizeof(float)) != hipSuccess) {
@@ -615,15 +616,36 @@ hipError_t launch_csr_merge(const CSRMatrix* A, CsrAux* aux, const float* d_x, f
             carry_val = fresh.val;
         }
     }
+    // Past kMaxExtraCarry streams (a caller that makes a new stream per call would otherwise grow the list for ever —
+    // and a kept pair cannot be handed to another stream while its owner may still be running): this call borrows a
+    // pair from the stream-ordered allocator and gives it back behind its own kernels.
+    bool borrowed = false;
+    if (!carry_row) {
+        if (hipMallocAsync(reinterpret_cast<void**>(&carry_row), num_tiles * sizeof(int), s) != hipSuccess ||
+            hipMallocAsync(reinterpret_cast<void**>(&carry_val), num_tiles * sizeof(float), s) != hipSuccess) {
+            (void)hipGetLastError();
+            if (carry_row) (void)hipFreeAsync(carry_row, s);
+            return hipErrorOutOfMemory;
+        }
+        borrowed = true;
+    }
 
     merge_tile_kernel<<<num_tiles, kBlock, 0, s>>>(A->num_rows, A->nnz, A->d_row_ptrs,
                                                    A->d_col_indices, A->d_values, d_x,
                                                    aux->d_tile_rows, d_y, carry_row, carry_val);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) {
+        if (borrowed) { (void)hipFreeAsync(carry_row, s); (void)hipFreeAsync(carry_val, s); }
+        return e;
+    }
     merge_fixup_kernel<<<(num_tiles + kBlock - 1) / kBlock, kBlock, 0, s>>>(
         A->num_rows, num_tiles, carry_row, carry_val, d_y);
-    return hipGetLastError();
+    e = hipGetLastError();
+    if (borrowed) {
+        (void)hipFreeAsync(carry_row, s);
+        (void)hipFreeAsync(carry_val, s);
+    }
+    return e;
 }
 
 hipError_t launch_ell(const ELLMatrix* A, const float* d_x, float* d_y, hipStream_t s) {

@@ -312,6 +312,11 @@ hipError_t pr_step(const PrShard& sh, const float* r_old, float* r_new, float da
         const bool long_done = sh.expanded_long;
         sh.expanded_strips = 0;
         sh.expanded_long = false;
+        // Host threads may share a matrix and a stream (a pagerank() loop beside an spmv_csr call): the two launches
+        // of a step go out together, like tiled_spmv's pair, or another pair's expand could land between them and
+        // overwrite the stream's product scratch.  (After a head start by pr_expand the caller orders the launches.)
+        std::unique_lock<std::mutex> pair(sh.tiled->launch_lock, std::defer_lock);
+        if (done == 0 && !long_done) pair.lock();
         if (done < sh.tiled->num_strips || !long_done) {
             const hipError_t e = tiled_pagerank_expand(*sh.tiled, done, sh.tiled->num_strips, !long_done, r_old, sh.d_state, s);
             if (e != hipSuccess) return e;
@@ -552,7 +557,6 @@ public:
                    && hipMalloc(&w.state, sizeof(detail::PrState)) == hipSuccess
                    && hipMalloc(reinterpret_cast<void**>(&w.dangling_count), sizeof(unsigned long long)) == hipSuccess
                    && hipHostMalloc(&w.pinned_state, 2 * sizeof(detail::PrState)) == hipSuccess
-                   && hipHostMalloc(reinterpret_cast<void**>(&w.pinned_ranks), len * sizeof(float)) == hipSuccess
                    && hipEventCreateWithFlags(&w.seen[0], hipEventDisableTiming) == hipSuccess
                    && hipEventCreateWithFlags(&w.seen[1], hipEventDisableTiming) == hipSuccess;
             if (!ok) return false;
@@ -587,7 +591,12 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     if (const char* env = std::getenv("SPMV_NUM_GPUS")) {
         const int gpus = std::atoi(env);
         if (gpus > 1 && adj->num_rows > 0 && adj->row_ptrs && (adj->nnz == 0 || (adj->col_indices && adj->values))) {
-            return pagerank_multi_gpu(adj, config, gpus);
+            // pagerank() always hands back an allocated ranks array (the reference's contract: callers index it
+            // unchecked); the empty result of a multi-device run that could not start or did not finish — fewer
+            // devices than asked for, no librccl, a device error — is therefore not passed on: one device does it
+            PageRankResult sharded = pagerank_multi_gpu(adj, config, gpus);
+            if (sharded.ranks) return sharded;
+            std::fprintf(stderr, "[spmv] SPMV_NUM_GPUS=%d: the multi-device run returned nothing; using one device\n", gpus);
         }
     }
 
@@ -663,6 +672,10 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     // every column's one stored value w (0 where the column has no entry): the reference's sequential fp32
     // column sum of k copies of w is 0 exactly when w == 0, so the mask is read off the weights.  Otherwise:
     // host scan when host arrays exist (reference semantics), else atomic column sums on the device.
+    if (ws->mask_valid && (ws->mask_cols != adj->d_col_indices || ws->mask_vals != adj->d_values || ws->mask_nnz != adj->nnz ||
+                           ws->mask_rows != adj->num_rows || ws->mask_num_cols != adj->num_cols)) {
+        ws->mask_valid = false;          // another matrix over the same row pointers, or arrays swapped on the handle
+    }
     if (ok && !ws->mask_valid) {
         unsigned long long num_dangling = 0;
         ok = hipMemsetAsync(ws->mask, 0, len, stream) == hipSuccess
@@ -694,6 +707,11 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
         if (ok) {
             ws->num_dangling = num_dangling;
             ws->mask_valid = true;
+            ws->mask_cols = adj->d_col_indices;
+            ws->mask_vals = adj->d_values;
+            ws->mask_nnz = adj->nnz;
+            ws->mask_rows = adj->num_rows;
+            ws->mask_num_cols = adj->num_cols;
         }
     }
     if (!ok) return result;
@@ -757,7 +775,12 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
             ok = hipMemcpyAsync(result.ranks, last, bytes, hipMemcpyDeviceToHost, stream) == hipSuccess
               && hipStreamSynchronize(stream) == hipSuccess;
         } else if (ok) {
-            // in pieces, so that the host copy of piece k runs while piece k + 1 crosses PCIe
+            // in pieces, so that the host copy of piece k runs while piece k + 1 crosses PCIe; the staging array is
+            // allocated by the first call that comes this way (large graphs get the pooled pinned result instead)
+            if (!ws->pinned_ranks) {
+                ok = hipHostMalloc(reinterpret_cast<void**>(&ws->pinned_ranks), ws->len * sizeof(float)) == hipSuccess;
+                if (!ok) { (void)hipGetLastError(); ws->pinned_ranks = nullptr; }
+            }
             const size_t piece = 4u << 20;          // floats
             size_t done = 0;
             hipEvent_t landed[2] = {ws->seen[0], ws->seen[1]};

@@ -40,10 +40,12 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -131,6 +133,9 @@ struct DeviceShard {
     CSRMatrix header;               // wraps the three arrays (side-table key for the tiled plan)
     detail::PrShard shard;
     ncclComm_t comm = nullptr;
+    // The communicator is used by this shard's host thread (collectives) and, on a failure elsewhere, by the failing
+    // thread (ncclCommAbort): both under comm_lock, and an aborted communicator is never touched again.
+    std::unique_ptr<std::mutex> comm_lock{new std::mutex};
     bool comm_aborted = false;      // ncclCommAbort already released it
     bool have_header = false;
     hipStream_t side_stream = nullptr;      // overlapped exchange: the collectives / copies run here
@@ -344,6 +349,7 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
     // another thread can wait on it).
     detail::PrState last_state{};
     Rendezvous meet(P);
+    std::atomic<bool> aborted{false};       // some thread failed: nobody starts another collective
     std::vector<detail::PrState*> pinned(P, nullptr);
     std::vector<std::array<hipEvent_t, 2>> seen(P, std::array<hipEvent_t, 2>{nullptr, nullptr});
     for (int p = 0; p < P && ok; ++p) {
@@ -355,7 +361,7 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
     auto drive = [&](int p) {
         DeviceShard& d = shards[p];
         bool fine = hipSetDevice(d.device) == hipSuccess;
-        for (int iter = 0; fine && iter < config->max_iterations; ++iter) {
+        for (int iter = 0; fine && !aborted.load() && iter < config->max_iterations; ++iter) {
             const float* r_old = d.r[iter & 1];
             float* r_new = d.r[(iter + 1) & 1];
             if (by_copies && iter > 0) {
@@ -391,7 +397,9 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
                                                           static_cast<size_t>(piece) * sizeof(float), hipMemcpyDeviceToDevice, xs) == hipSuccess;
                         }
                     } else {
-                        fine = api->AllGather(mine + p * piece, mine, static_cast<size_t>(piece), ncclFloat, d.comm, xs) == ncclSuccess;
+                        std::lock_guard<std::mutex> mine_only(*d.comm_lock);
+                        fine = !aborted.load() && !d.comm_aborted
+                            && api->AllGather(mine + p * piece, mine, static_cast<size_t>(piece), ncclFloat, d.comm, xs) == ncclSuccess;
                     }
                     if (fine && side) {
                         fine = hipEventRecord(d.block_done[c], xs) == hipSuccess
@@ -419,9 +427,14 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
             // Let nobody wait for this thread: release the rendezvous, and abort the collectives the peers may be
             // blocked in on the device (a rank that never joins would otherwise hang them).
             meet.fail();
+            aborted.store(true);
             if (api && api->CommAbort) {
                 for (DeviceShard& other : shards) {
-                    if (other.comm) (void)api->CommAbort(other.comm);
+                    std::lock_guard<std::mutex> one_at_a_time(*other.comm_lock);     // each communicator exactly once
+                    if (other.comm && !other.comm_aborted) {
+                        (void)api->CommAbort(other.comm);
+                        other.comm_aborted = true;
+                    }
                 }
             }
         }
@@ -439,9 +452,7 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
             for (std::thread& t : threads) t.join();
         }
         for (int p = 0; p < P; ++p) ok = ok && outcome[p];
-        if (!ok) {
-            for (DeviceShard& d : shards) d.comm_aborted = d.comm != nullptr && api && api->CommAbort;
-        }
+        // (a failing thread has aborted every communicator and marked it: release() destroys only the others)
     }
     if (ok) {
         ok = hipSetDevice(shards[0].device) == hipSuccess

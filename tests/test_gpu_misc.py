@@ -327,3 +327,75 @@ def test_host_threads_sharing_one_matrix(gpu, oracle):
     assert not failures, failures
     assert gpu.csr_has_tiled_plan(A)
     gpu.csr_destroy(A)
+
+
+def test_a_pagerank_loop_and_spmv_calls_share_a_matrix_and_a_stream(gpu, oracle):
+    """A host thread inside pagerank(A) (steps through the tiled engine: two launches around the stream's product
+    scratch) while others call spmv_csr(A, use_texture) on the same (default) stream: a step's pair of launches must
+    not be split by another pair's phase 1 (the plan's launch lock covers both, csrc/pagerank.hip pr_step)."""
+    import threading
+    n, k = 300_000, 8
+    rp, ci, _ = gpu.synth.uniform_csr(31, 0, n, n, k)
+    va = gpu.synth.column_stochastic_values(ci, n)
+    A = gpu.csr_from_arrays(n, n, rp, ci, va)
+    assert gpu.csr_to_gpu(A) == 0
+    cfg = gpu.PageRankConfig(0.85, 0.0, 12)
+    alone = gpu.pagerank(A, cfg)                      # builds the plan after four direct steps
+    assert gpu.csr_has_tiled_plan(A)
+    alone = np.array(gpu.pagerank(A, cfg).ranks, copy=True)       # all twelve steps through the plan
+    xs = [gpu.synth.vector(31, 40 + i, n) * np.float32(3 + i) for i in range(2)]
+    wants = [oracle.spmv_csr(rp, ci, va, x) for x in xs]
+    failures = []
+    gate = threading.Barrier(3)
+
+    def ranker():
+        try:
+            gate.wait(timeout=60)
+            for _ in range(6):
+                got = gpu.pagerank(A, cfg)
+                assert np.array_equal(np.asarray(got.ranks), alone), "pagerank() changed beside concurrent spmv_csr calls"
+        except Exception as exc:            # noqa: BLE001
+            failures.append(("pagerank", repr(exc)))
+
+    def multiplier(index):
+        try:
+            d_x, d_y = gpu.CudaBuffer(n), gpu.CudaBuffer(n)
+            d_x.copyFromHost(xs[index], n)
+            gate.wait(timeout=60)
+            for call in range(40):
+                assert gpu.spmv_csr(A, d_x, d_y, gpu.SpMVConfig(kernel_type=1, use_texture=True), n).error_code == 0
+                assert reorder_err(rp, ci, va, xs[index], wants[index], d_y.copyToHost(n)) <= 1e-5, (index, call)
+        except Exception as exc:            # noqa: BLE001
+            failures.append((index, repr(exc)))
+
+    threads = [threading.Thread(target=ranker)] + [threading.Thread(target=multiplier, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not failures, failures
+    gpu.csr_destroy(A)
+
+
+def test_merge_path_on_more_streams_than_the_matrix_keeps_scratch_for(gpu, oracle):
+    """Every new stream used to add a carry pair to the matrix for good; past eight streams a call now borrows its
+    pair from the stream-ordered allocator and returns it behind its kernels.  Twelve streams, results checked."""
+    torch = pytest.importorskip("torch")
+    rows, cols = 60_000, 50_000
+    lens = gpu.synth.power_law_lengths(5, rows, max_len=4000, n_cols=cols)
+    rp, ci, va = gpu.synth.stratified_csr(5, 0, lens, cols)
+    x = gpu.synth.vector(5, 1, cols)
+    want = oracle.spmv_csr(rp, ci, va, x)
+    A = gpu.csr_from_arrays(rows, cols, rp, ci, va)
+    assert gpu.csr_to_gpu(A) == 0
+    d_x = torch.from_numpy(x).cuda()
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    outs = [torch.empty(rows, dtype=torch.float32, device="cuda") for _ in streams]
+    torch.cuda.synchronize()
+    for _ in range(2):
+        for s, y in zip(streams, outs):
+            assert gpu.spmv_csr_async(A, d_x.data_ptr(), y.data_ptr(), gpu.SpMVConfig(kernel_type=2), cols, s.cuda_stream) == 0
+    torch.cuda.synchronize()
+    for y in outs:
+        assert reorder_err(rp, ci, va, x, want, y.cpu().numpy()) <= 1e-5
+    gpu.csr_destroy(A)

@@ -581,3 +581,33 @@ def test_top_k_on_the_device_for_large_vectors(gpu):
     result.ranks[5] = -1.0
     top = gpu.pagerank_top_k(result, n, 3)
     np.testing.assert_array_equal(np.array([r for _, r in top], np.float32), np.sort(result.ranks)[::-1][:3])
+
+
+def test_two_matrices_over_one_row_pointer_array_keep_their_own_dangling_masks(gpu, oracle):
+    """Every k-per-row graph has the same row-pointer array, and the per-matrix workspace (with the cached dangling
+    mask) is keyed by it: the mask must be recomputed when the column / value arrays under the handle are not the
+    ones it was computed for (the reference recomputes it every call, src/pagerank.cu:20-48)."""
+    torch = pytest.importorskip("torch")
+    n, k = 20_000, 8
+    rp, ci, _ = gpu.synth.uniform_csr(91, 0, n, n, k)
+    lonely = np.array([5, 777, 19_999], dtype=np.int32)            # nobody links to these in the second graph
+    ci2 = ci.copy()
+    hit = np.isin(ci2, lonely)
+    ci2[hit] = (ci2[hit] + 1) % n
+    assert not np.isin(ci2, lonely).any()
+    va1, va2 = gpu.synth.column_stochastic_values(ci, n), gpu.synth.column_stochastic_values(ci2, n)
+    dev = torch.device("cuda:0")
+    d_rp = torch.from_numpy(rp).to(dev)
+    t1 = (torch.from_numpy(ci).to(dev), torch.from_numpy(va1).to(dev))
+    t2 = (torch.from_numpy(ci2).to(dev), torch.from_numpy(va2).to(dev))
+    A1 = gpu.csr_wrap_device(n, n, ci.size, d_rp.data_ptr(), t1[0].data_ptr(), t1[1].data_ptr())
+    A2 = gpu.csr_wrap_device(n, n, ci2.size, d_rp.data_ptr(), t2[0].data_ptr(), t2[1].data_ptr())
+    cfg = gpu.PageRankConfig(0.85, 0.0, 6)
+    want1, *_ = oracle.pagerank(rp, ci, va1, num_cols=n, tolerance=0.0, max_iterations=6, wide_sums=True)
+    want2, *_ = oracle.pagerank(rp, ci2, va2, num_cols=n, tolerance=0.0, max_iterations=6, wide_sums=True)
+    assert worst_rel(want1, want2) > 1e-3                           # the two graphs do differ
+    for _ in range(2):                                              # back and forth: neither inherits the other's mask
+        compare(gpu.pagerank(A1, cfg).ranks, want1)
+        compare(gpu.pagerank(A2, cfg).ranks, want2)
+    gpu.csr_destroy(A1)
+    gpu.csr_destroy(A2)

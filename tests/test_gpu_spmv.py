@@ -357,6 +357,48 @@ def test_tiled_engine_is_reproducible_run_to_run_and_across_plan_rebuilds(gpu):
         A.close()
 
 
+def test_rows_whose_products_span_more_than_fp64_can_hold_stay_within_one_ulp(gpu, oracle):
+    """The limit of the reproducibility claim.  A tile adds fp32 products into fp64 accumulators
+    in arrival order; that is order-free only while a row's products span < 29 binades (53 - 24 bits).  Rows built
+    to break it: 2^40 and 2^16 in one strip (2^16 is exactly half an fp32 ulp of 2^40) and eight times 2^-14 in eight
+    other strips (each below half an fp64 ulp of 2^40: absorbed one by one if they arrive after the big terms, 2^-11
+    together if they meet first).  The exact sum rounds UP to 2^40 + 2^17, the reference's left-to-right fp32 sum
+    gives 2^40; the engine may return either — one fp32 ulp apart, far inside the 1e-5 parity bound — and which one
+    may change from run to run.  Every other row (narrow range) must still be bit-equal across runs."""
+    rows, cols, special = 200_000, 262_144, 20_000
+    base_rp, base_ci, base_va = gpu.synth.uniform_csr(17, 0, rows, cols, 6)
+    strip = 16_384
+    extra_cols = np.concatenate([[3, 7], strip * np.arange(2, 10) + 11]).astype(np.int32)        # ascending, ten strips
+    extra_vals = np.concatenate([[2.0 ** 40, 2.0 ** 16], np.full(8, 2.0 ** -14)]).astype(np.float32)
+    lens = np.full(rows, 6, dtype=np.int64)
+    lens[:special] = extra_cols.size
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate([np.tile(extra_cols, special), base_ci[6 * special:]]).astype(np.int32)
+    va = np.concatenate([np.tile(extra_vals, special), base_va[6 * special:]]).astype(np.float32)
+    x = np.ones(cols, dtype=np.float32)
+    want = oracle.spmv_csr(rp, ci, va, x)
+    assert (want[:special] == np.float32(2.0 ** 40)).all()
+    A = gpu.csr_from_arrays(rows, cols, rp, ci, va)
+    assert gpu.csr_to_gpu(A) == 0
+    d_x, d_y = gpu.CudaBuffer(cols), gpu.CudaBuffer(rows)
+    d_x.copyFromHost(x, cols)
+    allowed = {np.float32(2.0 ** 40), np.float32(2.0 ** 40 + 2.0 ** 17)}
+    outs = []
+    for _ in range(6):
+        assert gpu.spmv_csr(A, d_x, d_y, gpu.SpMVConfig(1, 256, True), cols).error_code == 0
+        got = d_y.copyToHost(rows)
+        assert set(np.unique(got[:special]).tolist()) <= {float(v) for v in allowed}, np.unique(got[:special])
+        assert reorder_err(rp, ci, va, x, want, got) <= 1e-5
+        outs.append(got.view(np.uint32).copy())
+    assert gpu.csr_has_tiled_plan(A)
+    for other in outs[1:]:
+        assert np.array_equal(outs[0][special:], other[special:])          # narrow rows: bit-equal, as claimed
+    flips = int(sum(np.count_nonzero(outs[0][:special] != other[:special]) for other in outs[1:]))
+    rounded_up = int(np.count_nonzero(outs[0][:special].view(np.float32) != np.float32(2.0 ** 40)))
+    print("wide-range rows: %d of %d rounded up in run 0, %d row results changed between runs" % (rounded_up, special, flips))
+    gpu.csr_destroy(A)
+
+
 def test_both_placing_passes_build_the_same_plan(gpu, monkeypatch):
     """The builder's placing pass has two forms — slots assembled in LDS and stored as contiguous segments, or one
     scattered store per entry (what batches with long rows inside, or with more skip markers than the staging

@@ -21,3 +21,4 @@ def test_small_and_awkward_shapes_through_the_tiled_engine(gpu):
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "tiled small shapes:" in out.stdout
+    assert "reference fixtures through the tiled engine: 13 cases" in out.stdout

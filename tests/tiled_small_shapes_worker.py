@@ -118,6 +118,45 @@ def main():
         spmv.csr_destroy(A)
         cases += 1
     print("tiled small shapes: %d cases, %d through the tiled engine, worst error %.3g" % (cases, planned_cases, worst))
+    golden_fixtures()
+
+
+def golden_fixtures():
+    """The 13 inputs of tests/golden/ref_cases.npz through the tiled engine (CSR as VECTOR_CSR and MERGE_PATH with
+    use_texture, the ELL slabs with use_texture), against the y the REFERENCE's own spmv_cpu_csr / spmv_cpu_ell
+    produced for them (/root/reference/src/spmv_cpu.cpp:6-32, recorded by tests/golden/make_golden.py)."""
+    import ctypes
+    data = np.load(os.path.join(ROOT, "tests", "golden", "ref_cases.npz"), allow_pickle=False)
+    through_plan = 0
+    for name in (str(n) for n in data["case_names"]):
+        rp, ci, va = data[f"{name}/csr_row_ptrs"], data[f"{name}/csr_col_indices"], data[f"{name}/csr_values"]
+        x, want_csr, want_ell = data[f"{name}/x"], data[f"{name}/y_csr"], data[f"{name}/y_ell"]
+        rows, cols, nnz = (int(v) for v in data[f"{name}/csr_shape"])
+        d_x, d_y = spmv.CudaBuffer(max(cols, 1)), spmv.CudaBuffer(max(rows, 1))
+        d_x.copyFromHost(x, cols)
+        A = spmv.csr_from_arrays(rows, cols, rp, ci, va)
+        assert spmv.csr_to_gpu(A) == 0
+        for kernel in (1, 2):
+            res = spmv.spmv_csr(A, d_x, d_y, spmv.SpMVConfig(kernel_type=kernel, use_texture=True), cols)
+            assert res.error_code == 0, (name, kernel, res.error_code)
+            err = reorder_err(rp, ci, va, x, want_csr, d_y.copyToHost(rows))
+            assert err <= 1e-5, (name, kernel, err)
+        through_plan += int(bool(spmv.csr_has_tiled_plan(A)))
+        spmv.csr_destroy(A)
+        erows, ecols_n, kk = (int(v) for v in data[f"{name}/ell_shape"])
+        E = spmv.ell_create(erows, ecols_n, kk)
+        ecols, evals = data[f"{name}/ell_col_indices"], data[f"{name}/ell_values"]
+        if ecols.size:
+            ctypes.memmove(E.contents.col_indices, ecols.ctypes.data, ecols.nbytes)
+            ctypes.memmove(E.contents.values, evals.ctypes.data, evals.nbytes)
+        assert spmv.ell_to_gpu(E) == 0
+        res = spmv.spmv_ell(E, d_x, d_y, spmv.SpMVConfig(kernel_type=spmv.SpMVConfig.ELL_KERNEL, use_texture=True), cols)
+        assert res.error_code == 0, (name, "ell", res.error_code)
+        err = reorder_err(rp, ci, va, x, want_ell, d_y.copyToHost(rows))
+        assert err <= 1e-5, (name, "ell", err)
+        spmv.ell_destroy(E)
+    assert through_plan >= 8, through_plan          # the non-trivial cases did go through a plan
+    print("reference fixtures through the tiled engine: 13 cases, %d with a plan" % through_plan)
 
 
 if __name__ == "__main__":

@@ -625,8 +625,11 @@ def parity_report(spmv, wl, seed):
         x = spmv.synth.vector(seed, 1, A.cols)
         want = oracle.spmv_csr(rp, ci, va, x).astype(np.float64)
         prod = np.abs(va.astype(np.float64) * x.astype(np.float64)[ci])
-        csum = np.concatenate([[0.0], np.cumsum(prod)])
-        abs_sum = csum[rp[1:].astype(np.int64)] - csum[rp[:-1].astype(np.int64)]
+        rp64 = rp.astype(np.int64)
+        abs_sum = np.zeros(rp64.size - 1, dtype=np.float64)
+        nonempty = rp64[1:] > rp64[:-1]
+        if prod.size and nonempty.any():
+            abs_sum[nonempty] = np.add.reduceat(prod, rp64[:-1][nonempty])
         d_x, d_y = spmv.CudaBuffer(A.cols), spmv.CudaBuffer(A.rows)
         d_x.copyFromHost(x, A.cols)
         for kt, label in kernels:

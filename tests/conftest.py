@@ -65,8 +65,12 @@ def reorder_err(row_ptrs, cols, vals, x, expected, actual):
     exactly the relative error of the north-star (1e-5)."""
     row_ptrs = np.asarray(row_ptrs, dtype=np.int64)
     prod = np.abs(np.asarray(vals, np.float64) * np.asarray(x, np.float64)[np.asarray(cols)])
-    csum = np.concatenate([[0.0], np.cumsum(prod)])
-    abs_sum = csum[row_ptrs[1:]] - csum[row_ptrs[:-1]]
+    # per-row sums row by row (differences of one running sum over the whole matrix lose the small rows as soon as
+    # some row holds huge products: test_rows_whose_products_span_more_than_fp64_can_hold...)
+    abs_sum = np.zeros(row_ptrs.size - 1, dtype=np.float64)
+    nonempty = row_ptrs[1:] > row_ptrs[:-1]
+    if prod.size and nonempty.any():
+        abs_sum[nonempty] = np.add.reduceat(prod, row_ptrs[:-1][nonempty])
     expected = np.asarray(expected, np.float64)
     actual = np.asarray(actual, np.float64)
     ok_nonfinite = (~np.isfinite(expected)) & ((expected == actual) | (np.isnan(expected) & np.isnan(actual)))

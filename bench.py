@@ -191,10 +191,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # a peer that never arrives, or a collective a peer never joins, ends as an error after this long, not as a hang
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("SPMV_DIST_TIMEOUT", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     # The bench matrix is column-stochastic (a_ij = 1 / outdeg(j)), a structure the tiled engine can
     # exploit by folding the values into one weight per column.  The headline is

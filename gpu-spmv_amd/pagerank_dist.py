@@ -49,6 +49,86 @@ import torch.distributed as dist
 from . import PrStatus, csr_destroy, csr_wrap_device, lib
 
 TAIL = 4   # floats appended to every slice when world > 1 (two doubles)
+EXIT_PEER_FAILED = 70      # exit code of a rank that had to leave because ANOTHER rank failed while it was blocked
+
+
+class PeerFailure(RuntimeError):
+    """Another rank of the job reported a failure (or the rendezvous store went away): this rank stops too."""
+
+
+class FailureWatch:
+    """What one failing rank costs the others (failure detection).
+
+    A collective has no way out when a peer never joins it: RCCL waits on the device, gloo in the host call.  So
+    every rank keeps a small daemon thread that looks at one key of the job's rendezvous store a few times per
+    second.  A rank whose loop raises writes its story under that key (`report`) and re-raises — the process ends
+    non-zero by the ordinary route.  A rank that sees the key first gives its main thread `grace` seconds to notice (`check()` is called at the top of every iteration and
+    raises PeerFailure, an ordinary exception the caller may handle); a main thread that does not — because it
+    sits inside the collective the failed rank will never join — is taken down with the process
+    (os._exit(EXIT_PEER_FAILED)), which is what releases the GPU side too.  Nobody hangs, every exit is non-zero.
+    """
+    KEY = "spmv_amd/rank_failed"
+
+    def __init__(self, rank, world, store=None, poll=0.25, grace=5.0):
+        import threading
+        self.rank, self.world, self.poll, self.grace = rank, world, poll, grace
+        self.store = store
+        self.peer_failed = None          # the failed rank's story, once seen
+        self.acknowledged = False        # the main thread has seen it (it is on its way out by itself)
+        self._stop = threading.Event()
+        self._thread = None
+        if self.store is None and world > 1 and dist.is_available() and dist.is_initialized():
+            try:
+                from torch.distributed.distributed_c10d import _get_default_store
+                self.store = dist.PrefixStore("spmv_amd_watch", _get_default_store())
+            except Exception:           # noqa: BLE001 - no store, no watch
+                self.store = None
+        if self.store is not None and world > 1:
+            self._thread = threading.Thread(target=self._loop, name="spmv-failure-watch", daemon=True)
+            self._thread.start()
+
+    def _loop(self):
+        import os
+        import sys
+        import time
+        while not self._stop.wait(self.poll):
+            try:
+                failed = self.store.check([self.KEY])
+                story = self.store.get(self.KEY).decode(errors="replace") if failed else None
+            except Exception:           # noqa: BLE001
+                # The store lives in rank 0's process.  Losing it is what an orderly end of rank 0 looks like as well,
+                # so it is not read as a failure: a rank that dies without a word is the launcher's business
+                # (torch.distributed.run and mp.spawn both end the other workers when one exits non-zero).
+                return
+            if not failed:
+                continue
+            self.peer_failed = story
+            deadline = time.time() + self.grace
+            while time.time() < deadline:
+                if self.acknowledged or self._stop.is_set():
+                    return
+                time.sleep(0.05)
+            print("[spmv] rank %d: another rank failed (%s) and this rank is blocked in the exchange: leaving with exit "
+                  "code %d" % (self.rank, story, EXIT_PEER_FAILED), file=sys.stderr, flush=True)
+            os._exit(EXIT_PEER_FAILED)
+
+    def check(self):
+        """Top of every iteration: cheap (one attribute), raises once a peer has failed."""
+        if self.peer_failed is not None:
+            self.acknowledged = True
+            raise PeerFailure("rank %d stops: %s" % (self.rank, self.peer_failed))
+
+    def report(self, exc):
+        """This rank is failing with `exc`: tell the others before going down."""
+        if self.store is None or isinstance(exc, PeerFailure):
+            return
+        try:
+            self.store.set(self.KEY, "rank %d: %r" % (self.rank, exc))
+        except Exception:               # noqa: BLE001 - best effort on the way out
+            pass
+
+    def stop(self):
+        self._stop.set()
 
 
 class Layout:
@@ -327,9 +407,11 @@ class ShardedPageRank:
     """The host loop.  `engine` is a HipEngine (product) or any object with the same
     methods (the CPU test double in tests/test_distributed_gloo.py)."""
 
-    def __init__(self, engine, layout: Layout, group=None, device=None):
+    def __init__(self, engine, layout: Layout, group=None, device=None, watch=None):
         self.engine, self.layout, self.group = engine, layout, group
         self.n, self.rank, self.world = layout.n, layout.rank, layout.world
+        # one failing rank must not leave the others inside a collective for ever (FailureWatch above)
+        self.watch = watch if watch is not None else FailureWatch(self.rank, self.world)
         self.device = device if device is not None else getattr(engine, "device", torch.device("cpu"))
         # The two rank vectors.  On a GPU they are plain hipMalloc allocations made through the C ABI
         # (base pointers, so they can be exported with hipIpcGetMemHandle for the push exchange) and
@@ -377,6 +459,7 @@ class ShardedPageRank:
         """Unmap the peers' vectors, then (after a barrier when ranks share mappings) free the rank
         vectors.  The engine is closed by its owner."""
         had_peers = bool(self._peer_keepalive)
+        self.watch.stop()
         self.close_peers()
         if self.world > 1 and dist.is_available() and dist.is_initialized():
             if self.device.type == "cuda":
@@ -502,6 +585,14 @@ class ShardedPageRank:
 
     def iterate(self, k, damping, tolerance):
         """Enqueue iteration k (0-based): r[k & 1] -> r[(k + 1) & 1]."""
+        self.watch.check()
+        try:
+            self._iterate(k, damping, tolerance)
+        except Exception as exc:            # noqa: BLE001 - told to the peers, then raised as it is
+            self.watch.report(exc)
+            raise
+
+    def _iterate(self, k, damping, tolerance):
         r_old, r_new = self.r[k & 1], self.r[(k + 1) & 1]
         if not self.layout.exchange:
             if hasattr(self.engine, "step_and_commit"):
@@ -546,12 +637,16 @@ class ShardedPageRank:
         """Full PageRank; returns (ranks[n] float32 numpy, iterations, final_residual, converged).
         Steps enqueued after convergence are no-ops on every rank (device-side `done` flag),
         so `check_every` > 1 only trades host syncs for a few empty launches."""
-        self.reset()
-        for k in range(max_iterations):
-            self.iterate(k, damping, tolerance)
-            if (k + 1) % check_every == 0 and self.engine.status()[3]:
-                break
-        iterations, residual, converged, _ = self.engine.status()
+        try:
+            self.reset()
+            for k in range(max_iterations):
+                self.iterate(k, damping, tolerance)
+                if (k + 1) % check_every == 0 and self.engine.status()[3]:
+                    break
+            iterations, residual, converged, _ = self.engine.status()
+        except Exception as exc:            # noqa: BLE001 - an engine error (SpMVError from the C ABI) or a failed collective
+            self.watch.report(exc)
+            raise
         last = self.r[iterations & 1][self._pos].to("cpu").numpy().copy()
         total = np.float32(last.sum(dtype=np.float64))
         if total > 0:

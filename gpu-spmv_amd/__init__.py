@@ -25,7 +25,7 @@ from ctypes import c_size_t, c_uint8, c_uint64, c_void_p
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspmv_amd.so")
+LIB_PATH = os.environ.get("SPMV_AMD_LIB") or os.path.join(_HERE, "lib", "libspmv_amd.so")   # SPMV_AMD_LIB: an A/B build of the same library (tools/)
 
 
 class LibraryNotBuilt(ImportError):

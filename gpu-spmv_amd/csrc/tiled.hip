@@ -1163,6 +1163,9 @@ __device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_in
         for (int j = 0; j < kRuns; ++j) {
             const int k = min(group + j - window_first, 63);
             ps.begin[j] = __builtin_amdgcn_readlane(window.x, k);
+#if defined(SPMV_PROBE_PHASE2) && SPMV_PROBE_PHASE2 == 3      // timing probe: as if products and deltas were stored TILE-major (a tile's runs
+            ps.begin[j] = (tile_index * num_strips + min(group + j, num_strips - 1)) * 256;     // back to back, 256-slot pitch; C5 only; results wrong)
+#endif
             ps.len[j] = group + j < run_hi ? __builtin_amdgcn_readlane(window.y, k) : 0;
             ps.longest = max(ps.longest, ps.len[j]);
         }
@@ -1202,6 +1205,9 @@ __device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_in
     };
 
     int row_base[kRuns];                   // wave-uniform: row the run's previous chunk ended at
+#if defined(SPMV_PROBE_PHASE2)
+    float probe_sum = 0.f;
+#endif
     auto process = [&](const Pass& ps) {
         const unsigned int i = static_cast<unsigned int>(ps.done) + E * lane;
 #pragma unroll
@@ -1230,11 +1236,24 @@ __device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_in
             // instruction are the hardware's business; gfx950 runs it at 3.5 lanes/clk/CU on random rows,
             // the fp32 form at 0.38 — tools/lds_bench.hip).  Skip markers aim at a per-lane spare word, so
             // nothing here needs an execution mask.
+#if defined(SPMV_PROBE_PHASE2) && SPMV_PROBE_PHASE2 == 1      // timing probe: plain LDS stores where the adds go (results wrong)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                double* target = delta[e] != kSkip ? &tile[lane_base + upto[e]] : &spare[lane];
+                *reinterpret_cast<volatile double*>(target) = static_cast<double>(ps.p[j][e]);
+            }
+#elif defined(SPMV_PROBE_PHASE2) && SPMV_PROBE_PHASE2 == 2    // timing probe: no LDS traffic for the adds (results wrong)
+            {
+#pragma unroll
+                for (int e = 0; e < E; ++e) probe_sum += ps.p[j][e] * static_cast<float>(lane_base + upto[e]);
+            }
+#else
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 double* target = delta[e] != kSkip ? &tile[lane_base + upto[e]] : &spare[lane];
                 atomicAdd(target, static_cast<double>(ps.p[j][e]));
             }
+#endif
         }
     };
 
@@ -1250,6 +1269,154 @@ __device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_in
         if (a.valid) issue_loads(a);
         process(b);
     }
+#if defined(SPMV_PROBE_PHASE2)
+    tile[threadIdx.x] += static_cast<double>(probe_sum);
+#endif
+    __syncthreads();
+}
+
+#ifndef SPMV_STREAM_SEGS
+#define SPMV_STREAM_SEGS 3      // segments per pass: 2 / 3 / 4 measured 492 / 482 / 483 us on C5, 47.9 / 48.7 / 51.9 on C2, 41.6 / 42.4 / 44.2 on C4
+#endif
+// STREAM form of the same accumulation (round 3).  Phase 2 is bound by vector-instruction issue, not by its loads
+// or its LDS adds (profiles/r03_phase2_probes.txt: the kernel without any LDS traffic for the adds runs in 197 us
+// instead of 208, reading a tile's runs back to back instead of one per strip in 193-197 us; 78 M wave64 VALU
+// instructions x 4 cycles = 145 us per SIMD).  A third of the passes of the run-by-run form are tails: runs average
+// 258 slots on C5 and a pass takes 256.  Here the runs a wavefront owns are ONE stream of slots, 256 per pass whatever
+// the run boundaries: a pass is up to kSegs SEGMENTS (the end of one run, whole short runs, the start of the next),
+// every lane picks its segment's base by comparing its lane number with the segments' first lanes, the row of a slot
+// is its wave-wide prefix sum minus the prefix sum at the end of the previous segment (read with v_readlane: the
+// boundaries are wave-uniform), and the run that continues into the next pass carries its row over in a scalar.
+// Same slots, same rows, same fp64 adds: bit-identical results.
+template <int kReduceBlock, int kSegs>
+__device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int tile_index, int num_strips, int num_rows,
+                                                       const int2* __restrict__ cells_t,
+                                                       const float* __restrict__ prod,
+                                                       const unsigned char* __restrict__ a_drow,
+                                                       const LongSeeds seeds) {
+    __shared__ double spare[64];           // where a lane's slots without an entry "add" (never read)
+    const long long first = static_cast<long long>(tile_index) * R;
+    for (int i = threadIdx.x; i < R; i += kReduceBlock) tile[i] = 0.0;
+    if (seeds.tile_first) {
+        __syncthreads();
+        for (int k = seeds.tile_first[tile_index] + threadIdx.x; k < seeds.tile_first[tile_index + 1]; k += kReduceBlock) {
+            double total = 0.0;                         // a long row's chunk sums, in chunk order
+            for (int c = seeds.first_chunk[k]; c < seeds.first_chunk[k + 1]; ++c) total += static_cast<double>(seeds.chunk_sum[c]);
+            tile[seeds.rows[k] - first] = total;
+        }
+    }
+    __syncthreads();
+
+    constexpr int kSpan = 256;             // slots per pass: four per lane
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    constexpr int kWaves = kReduceBlock / 64;
+    const int per_wave = (num_strips + kWaves - 1) / kWaves;
+    const int run_lo = min(num_strips, wave * per_wave), run_hi = min(num_strips, run_lo + per_wave);
+    const int2* mine = cells_t + static_cast<long long>(tile_index) * num_strips;
+
+    struct Pass {
+        bool valid, fresh0, open_end;      // fresh0: segment 0 starts a run; open_end: the last segment's run goes on in the next pass
+        int groups;                        // 4-slot groups (= lanes) in use
+        int base[kSegs];                   // slot index lane 0 WOULD read if it belonged to the segment: a lane reads base + 4 * lane
+        int start[kSegs];                  // first lane of the segment
+        int last;                          // the last segment that holds slots
+        f32x4 p;
+        unsigned int d;
+    };
+    int row_carry = 0;                     // wave-uniform: the row the open run has reached (0 at a run's start)
+
+    // The (begin, length) records of the wavefront's runs come 64 at a time (lane l holds run window_first + l); inside
+    // a window everything below is scalar arithmetic on v_readlane'd values — no load but the two of a pass, so the
+    // compiler's s_waitcnt bookkeeping stays exact.  A pass never straddles two windows (the stream is cut there).
+    for (int window_first = run_lo; window_first < run_hi; window_first += 64) {
+        int2 window = window_first + lane < run_hi ? mine[window_first + lane] : make_int2(0, 0);
+        // the records are waited for HERE, once: read for the first time inside the loop below, the compiler would wait
+        // for them (vmcnt(0): everything in flight, the passes' own loads included) at every run it opens
+        asm volatile("; window records settled" : "+v"(window.x), "+v"(window.y));
+        const int window_runs = min(64, run_hi - window_first);
+        int next_run = 0, cur_begin = 0, cur_len = 0, off = 0;     // the stream cursor (wave-uniform)
+        row_carry = 0;
+
+        auto build = [&](Pass& ps) {
+            int filled = 0;
+            ps.fresh0 = true;
+            ps.last = 0;
+#pragma unroll
+            for (int k = 0; k < kSegs; ++k) {
+                while (off >= cur_len && next_run < window_runs) {       // step to the next run that holds slots (banded matrices: most are empty)
+                    const int idx = __builtin_amdgcn_readfirstlane(next_run);
+                    cur_begin = __builtin_amdgcn_readlane(window.x, idx);
+                    cur_len = __builtin_amdgcn_readlane(window.y, idx);
+                    off = 0;
+                    ++next_run;
+                }
+                const int take = max(min(cur_len - off, kSpan - filled), 0);
+                if (k == 0) ps.fresh0 = off == 0;
+                ps.base[k] = cur_begin + off - filled;
+                ps.start[k] = filled >> 2;
+                ps.last = take > 0 ? k : ps.last;
+                filled += take;
+                off += take;
+            }
+            ps.open_end = off < cur_len;
+            ps.groups = filled >> 2;
+            ps.valid = filled > 0;
+        };
+        auto issue_loads = [&](Pass& ps) {
+            // lanes past the pass's end re-read its last group (same cache line) and are masked below; a pass behind the
+            // stream's end (nothing in it) still issues its two loads — of slot 0 —, so that every pass costs the
+            // counters the same and the waits in front of process() stay "all but the newer pass's loads"
+            const int at = max(min(lane, ps.groups - 1), 0);
+            int base = ps.valid ? ps.base[0] : 0;
+#pragma unroll
+            for (int k = 1; k < kSegs; ++k) base = at >= ps.start[k] && ps.valid ? ps.base[k] : base;
+            const unsigned int slot = static_cast<unsigned int>(base + 4 * at);
+            ps.p = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(prod) + (static_cast<size_t>(slot) << 2));
+            ps.d = *reinterpret_cast<const unsigned int*>(a_drow + slot);
+        };
+        auto process = [&](const Pass& ps) {
+            const unsigned int word = lane < ps.groups ? ps.d : 0xFFFFFFFFu;
+            int delta[4], upto[4], sum = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                delta[e] = (word >> (8 * e)) & 0xFF;
+                sum += delta[e];
+                upto[e] = sum;
+            }
+            const int incl = wave_inclusive_scan(sum);
+            // a segment behind the first starts a run: its rows count from the prefix sum at the end of the segment before it
+            int origin = ps.fresh0 ? 0 : row_carry;
+            int lane_origin = origin;
+#pragma unroll
+            for (int k = 1; k < kSegs; ++k) {
+                const int before = __builtin_amdgcn_readlane(incl, max(ps.start[k] - 1, 0));
+                const int mine_k = ps.start[k] > 0 ? -before : 0;
+                lane_origin = lane >= ps.start[k] ? mine_k : lane_origin;
+                origin = k <= ps.last ? mine_k : origin;
+            }
+            const int lane_base = lane_origin + incl - sum;
+            row_carry = ps.open_end ? origin + __builtin_amdgcn_readlane(incl, max(ps.groups - 1, 0)) : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double* target = delta[e] != kSkip ? &tile[lane_base + upto[e]] : &spare[lane];
+                atomicAdd(target, static_cast<double>(ps.p[e]));
+            }
+        };
+
+        Pass a, b;
+        build(a);
+        issue_loads(a);
+        while (a.valid) {
+            build(b);
+            issue_loads(b);
+            process(a);
+            if (!b.valid) break;
+            build(a);
+            issue_loads(a);
+            process(b);
+        }
+    }
     __syncthreads();
 }
 
@@ -1264,7 +1431,8 @@ void tiled_reduce_kernel(int R, int num_tiles, const int2* __restrict__ cells_t,
     extern __shared__ double tile[];
     const int tile_index = xcd_contiguous(blockIdx.x, num_tiles);
     if (tile_index < 0) return;
-    tile_accumulate<kReduceBlock, E, kRuns>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_drow, seeds);
+    if constexpr (kRuns == 0) tile_accumulate_stream<kReduceBlock, SPMV_STREAM_SEGS>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_drow, seeds);
+    else tile_accumulate<kReduceBlock, E, kRuns>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_drow, seeds);
     const long long first = static_cast<long long>(tile_index) * R;
     for (int i = threadIdx.x; i < R && first + i < num_rows; i += kReduceBlock) y[first + i] = static_cast<float>(tile[i]);
 }
@@ -1285,7 +1453,8 @@ void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__
     extern __shared__ double tile[];
     const int tile_index = xcd_contiguous(blockIdx.x, num_tiles);
     if (tile_index < 0) return;
-    tile_accumulate<kReduceBlock, E, kRuns>(tile, R, tile_index, num_strips, local_rows, cells_t, prod, a_drow, seeds);
+    if constexpr (kRuns == 0) tile_accumulate_stream<kReduceBlock, SPMV_STREAM_SEGS>(tile, R, tile_index, num_strips, local_rows, cells_t, prod, a_drow, seeds);
+    else tile_accumulate<kReduceBlock, E, kRuns>(tile, R, tile_index, num_strips, local_rows, cells_t, prod, a_drow, seeds);
 
     const float teleport = __fdiv_rn(1.0f - damping, static_cast<float>(n_global));
     const float dangling_term = __fdiv_rn(__fmul_rn(damping, state->dangling_sum),
@@ -1453,7 +1622,17 @@ hipError_t launch_reduce_as(const TiledPlan& plan, const Scratch& sc, float* d_y
     return hipGetLastError();
 }
 
+// SPMV_TILED_STREAM=0 brings the run-by-run form of phase 2 back (A/B runs)
+bool stream_form() {
+    static const bool on = [] {
+        const char* env = std::getenv("SPMV_TILED_STREAM");
+        return !(env && env[0] == '0');
+    }();
+    return on;
+}
+
 hipError_t launch_reduce(const TiledPlan& plan, const Scratch& sc, float* d_y, hipStream_t s) {
+    if (stream_form()) return launch_reduce_as<1024, 4, 0>(plan, sc, d_y, s);
     switch (plan.lane_entries) {
         case 2:  return launch_reduce_as<1024, 2, 4>(plan, sc, d_y, s);
         case 4:  return launch_reduce_as<1024, 4, 2>(plan, sc, d_y, s);
@@ -1484,6 +1663,7 @@ hipError_t launch_pagerank_reduce(const TiledPlan& plan, const Scratch& sc, cons
 #define SPMV_PR_REDUCE(BLOCK, E, RUNS) \
     launch_pagerank_reduce_as<BLOCK, E, RUNS>(plan, sc, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state, \
                                               d_block_partials, push, s)
+    if (stream_form()) return SPMV_PR_REDUCE(1024, 4, 0);
     switch (plan.lane_entries) {
         case 2:  return SPMV_PR_REDUCE(1024, 2, 4);
         case 4:  return SPMV_PR_REDUCE(1024, 4, 2);

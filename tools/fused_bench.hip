@@ -34,6 +34,8 @@ struct Params {
     unsigned ring_bytes;
     const float* a_val; const unsigned short* a_lcol; const unsigned char* a_drow;
     const int2* cells_t;                        // [T * S] tile-major (begin, length)
+    const int2* cells_tm;                       // mode 6: the same table, begins in a TILE-major slot numbering
+    const unsigned char* a_drow_tm;             // mode 6: row deltas stored tile-major
     const int2* items;                          // [NG * S * H] (begin, end)
     const float* x; float* y; float* ring;
     unsigned* ctl;                              // [0..7] registration per XCC, [8] abort, [9] spin statistics
@@ -88,7 +90,7 @@ __device__ __forceinline__ bool spin_until_ge(const unsigned* addr, unsigned tar
 // item per lane; items known to be ready are walked in BATCHES by a loop that contains nothing but the P-deep software
 // pipeline (loads issued unconditionally, so the compiler's vmcnt bookkeeping stays exact); the batch's done signals go
 // out afterwards as one vector atomic.
-template <int P, int E>
+template <int P, int E, bool PLAIN = false>     // PLAIN: ordinary loads of the products (probes only: no hand-off is valid with them)
 __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     __shared__ unsigned sh[4];
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         const unsigned cu = ((xcc & 0xF) << 8) | ((hw >> 8) & 0xFF);
         const unsigned arrival = atomicAdd(&p.ctl[16 + cu], 1u);
-        const unsigned role = p.mode == 5 ? 0u : arrival & 1;    // 0 consumer, 1 producer (mode 5: every workgroup consumes)
+        const unsigned role = p.mode >= 5 ? 0u : arrival & 1;    // 0 consumer, 1 producer (mode 5: every workgroup consumes)
         sh[0] = role; sh[2] = 0; sh[3] = 0;
         sh[1] = atomicAdd(&p.ctl[10 + role], 1u);                // index inside the role
     }
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
         const int t = gi * G + member;
         const bool active = t < p.T;
         const unsigned* flags = ready + static_cast<size_t>(member) * p.ready_per_team + (gi * CW + cw) * p.SC;
-        int k0 = 0, known = (p.mode == 2 || p.mode == 3 || p.mode == 5) ? mine : 0, k = 0;
+        int k0 = 0, known = (p.mode == 2 || p.mode == 3 || p.mode >= 5) ? mine : 0, k = 0;
         int wbegin = 0, wlen = 0, wj = 0; unsigned wring = 0;      // the window: lane l holds item k0 + l
         auto load_window = [&]() {
             const int kk = k0 + lane;
@@ -198,7 +200,10 @@ __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
             if (kk < mine) {
                 const int n = cw + kk * CW;
                 wj = (gi * S + n) * H + hme;
-                if (active) {
+                if (active && p.mode == 6) {          // products and deltas both tile-major: a tile's runs are contiguous
+                    const int2 cell = p.cells_tm[static_cast<size_t>(t) * S + n];
+                    wbegin = cell.x; wlen = cell.y; wring = static_cast<unsigned>(cell.x);
+                } else if (active) {
                     const int2 cell = p.cells_t[static_cast<size_t>(t) * S + n];
                     const int ib = p.items[(static_cast<size_t>(gi) * S + n) * H + hme].x;
                     wbegin = cell.x; wlen = cell.y;
@@ -257,8 +262,8 @@ __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
                 for (int g4 = 0; g4 < kGroups; ++g4) {
                     const unsigned i = static_cast<unsigned>(ps.off) + E * lane + 4u * g4;
                     const unsigned at = min(i, static_cast<unsigned>(ps.len - 4));
-                    ps.prod[g4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rsrc, (ps.ring + at) * 4u, 0, 16));
-                    ps.dw[g4] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p.a_drow + ps.begin + at));
+                    ps.prod[g4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring_rsrc, (ps.ring + at) * 4u, 0, PLAIN ? 0 : 16));
+                    ps.dw[g4] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>((p.mode == 6 ? p.a_drow_tm : p.a_drow) + ps.begin + at));
                 }
             };
             int row_base = 0;
@@ -275,10 +280,23 @@ __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
                 const int incl = wave_inclusive_scan(sum);
                 const int lane_base = row_base + incl - sum;
                 row_base += __builtin_amdgcn_readlane(incl, 63);
+                if (p.mode == 7) {                    // probe: plain LDS stores where the atomic adds would go
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    double* target = delta[e] != 255 ? &tile[lane_base + upto[e]] : &spare[lane];
-                    atomicAdd(target, static_cast<double>(ps.prod[e / 4][e % 4]));
+                    for (int e = 0; e < E; ++e) {
+                        double* target = delta[e] != 255 ? &tile[lane_base + upto[e]] : &spare[lane];
+                        *reinterpret_cast<volatile double*>(target) = static_cast<double>(ps.prod[e / 4][e % 4]);
+                    }
+                } else if (p.mode == 8) {             // probe: no LDS traffic at all for the adds
+                    float fold = 0.f;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) fold += ps.prod[e / 4][e % 4] * static_cast<float>(lane_base + upto[e]);
+                    if (fold == 0.123456f) spare[lane] = fold;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        double* target = delta[e] != 255 ? &tile[lane_base + upto[e]] : &spare[lane];
+                        atomicAdd(target, static_cast<double>(ps.prod[e / 4][e % 4]));
+                    }
                 }
             };
             Pass ps[P];
@@ -295,7 +313,7 @@ __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
             }
             asm volatile("" ::: "memory");
             // every run of the batch is in registers or already added: release the slots
-            if (lane >= k - k0 && lane < kend - k0) __hip_atomic_fetch_add(done + static_cast<size_t>(wj) * kDoneStride, 1u, RLX, AGENT);
+            if (p.mode == 0 && lane >= k - k0 && lane < kend - k0) __hip_atomic_fetch_add(done + static_cast<size_t>(wj) * kDoneStride, 1u, RLX, AGENT);
             k = kend;
         }
         if (aborted) sh[3] = 1;
@@ -327,6 +345,13 @@ __global__ void fill_cells(const int* begin, const int* len, long long cells, in
             a_lcol[b + i] = (unsigned short)((z >> 10) % W);
             a_drow[b + i] = (unsigned char)((z >> 40) % dmax);
         }
+    }
+}
+__global__ void fill_drow(const int* begin, const int* len, long long cells, int R, unsigned char* a_drow) {
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (long long)gridDim.x * blockDim.x) {
+        const int b = begin[c], l = len[c];
+        const int dmax = R / (l + 1);
+        for (int i = 0; i < l; ++i) a_drow[b + i] = (unsigned char)((mix64((unsigned long long)(b + i) + 999) >> 40) % dmax);
     }
 }
 __global__ void fill_x(float* x, long long n) {
@@ -371,7 +396,7 @@ int main(int argc, char** argv) {
     const int L = (int)(entries / ((long long)S * T));         // mean run length
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
-    const int NT = 1, G = (argc > 8 && atoi(argv[8]) == 5) ? 2 * cus : cus;   // mode 5: phase 2 alone, two tiles per CU
+    const int NT = 1, G = (argc > 8 && atoi(argv[8]) >= 5) ? 2 * cus : cus;   // mode 5: phase 2 alone, two tiles per CU
     if (G % H) { printf("G %% H != 0\n"); return 1; }
     const int NG = (T + G - 1) / G, gpt = (NG + NT - 1) / NT;
     const int CW = 16;
@@ -388,8 +413,18 @@ int main(int argc, char** argv) {
         len[c] = l; begin[c] = (int)total; total += l;
     }
     begin[cells] = (int)total;
-    std::vector<int2> cells_t((size_t)T * S), items((size_t)NG * S * H);
+    std::vector<int2> cells_t((size_t)T * S), items((size_t)NG * S * H), cells_tm((size_t)T * S);
+    std::vector<int> begin_tm(cells), len_tm(cells);
     for (int t = 0; t < T; ++t) for (int s = 0; s < S; ++s) cells_t[(size_t)t * S + s] = make_int2(begin[(long long)s * T + t], len[(long long)s * T + t]);
+    {
+        long long run = 0;
+        for (int t = 0; t < T; ++t) for (int s = 0; s < S; ++s) {
+            const int l = len[(long long)s * T + t];
+            cells_tm[(size_t)t * S + s] = make_int2((int)run, l);
+            begin_tm[(size_t)t * S + s] = (int)run; len_tm[(size_t)t * S + s] = l;
+            run += l;
+        }
+    }
     unsigned slot_cap = 0;
     for (int g = 0; g < NG; ++g) for (int s = 0; s < S; ++s) for (int h = 0; h < H; ++h) {
         const int lo = std::min(T, g * G + h * (G / H)), hi = std::min(T, g * G + (h + 1) * (G / H));
@@ -398,7 +433,7 @@ int main(int argc, char** argv) {
         slot_cap = std::max(slot_cap, (unsigned)(e - b));
     }
     slot_cap = (slot_cap + 63) / 64 * 64;
-    const size_t ring_floats = (size_t)NT * G * D * slot_cap;
+    const size_t ring_floats = std::max((size_t)NT * G * D * slot_cap, (size_t)total + 64);
     if (ring_floats * 4 >= (1ull << 32)) { printf("ring too large\n"); return 1; }
     const int items_per_team = gpt * S * H, ready_per_team = (gpt * CW * SC + 63) / 64 * 64;     // ready: one mailbox per consumer
 
@@ -412,6 +447,12 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&x, (size_t)S * W * 4)); CHECK(hipMalloc(&y, (size_t)T * R * 4)); CHECK(hipMalloc(&yref, (size_t)T * R * 8));
     CHECK(hipMalloc(&ring, ring_floats * 4)); CHECK(hipMalloc(&d_begin, (cells + 1) * 4)); CHECK(hipMalloc(&d_len, cells * 4));
     CHECK(hipMalloc(&d_cells_t, cells_t.size() * 8)); CHECK(hipMalloc(&d_items, items.size() * 8));
+    int2* d_cells_tm; unsigned char* a_drow_tm; int *d_begin_tm, *d_len_tm;
+    CHECK(hipMalloc(&d_cells_tm, cells_tm.size() * 8)); CHECK(hipMalloc(&a_drow_tm, total + 64));
+    CHECK(hipMalloc(&d_begin_tm, cells * 4)); CHECK(hipMalloc(&d_len_tm, cells * 4));
+    CHECK(hipMemcpy(d_cells_tm, cells_tm.data(), cells_tm.size() * 8, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_begin_tm, begin_tm.data(), cells * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_len_tm, len_tm.data(), cells * 4, hipMemcpyHostToDevice));
     const size_t ctl_words = 16 + 4096;                      // registration, abort, statistics; per-CU arrival counters
     const size_t flag_words = ctl_words + (size_t)items_per_team * kDoneStride + (size_t)G * ready_per_team;
     CHECK(hipMalloc(&flags, flag_words * 4)); CHECK(hipMalloc(&bad, 8));
@@ -421,6 +462,7 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(d_items, items.data(), items.size() * 8, hipMemcpyHostToDevice));
     fill_cells<<<2048, 256>>>(d_begin, d_len, cells, T, R, W, a_val, a_lcol, a_drow);
     fill_x<<<2048, 256>>>(x, (long long)S * W);
+    fill_drow<<<2048, 256>>>(d_begin_tm, d_len_tm, cells, R, a_drow_tm);
     CHECK(hipMemset(yref, 0, (size_t)T * R * 8)); CHECK(hipMemset(ring, 0, ring_floats * 4));
     reference<<<4096, 256>>>(d_begin, d_len, cells, T, R, W, a_val, a_lcol, a_drow, x, yref);
     CHECK(hipDeviceSynchronize());
@@ -429,6 +471,7 @@ int main(int argc, char** argv) {
     p.S = S; p.T = T; p.R = R; p.W = W; p.G = G; p.H = H; p.D = D; p.NT = NT; p.NG = NG; p.gpt = gpt;
     p.num_rows = (int)rows; p.SC = SC; p.slot_cap = slot_cap; p.ring_bytes = (unsigned)(ring_floats * 4);
     p.a_val = a_val; p.a_lcol = a_lcol; p.a_drow = a_drow; p.cells_t = d_cells_t; p.items = d_items; p.x = x; p.y = y; p.ring = ring;
+    p.cells_tm = d_cells_tm; p.a_drow_tm = a_drow_tm;
     p.ctl = flags; p.done = flags + ctl_words; p.ready = flags + ctl_words + (size_t)items_per_team * kDoneStride;
     p.items_per_team = items_per_team; p.ready_per_team = ready_per_team; p.mode = 0;
     const size_t lds = std::max((size_t)W * 4, (size_t)R * 8);
@@ -439,10 +482,13 @@ int main(int argc, char** argv) {
         CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         kern<<<2 * cus, 1024, lds, 0>>>(p); } while (0)
         if (E == 8) { if (P == 2) GOS(2, 8); else if (P == 3) GOS(3, 8); else GOS(4, 8); }
+        else if (getenv("FUSED_PLAIN_LOADS")) { auto kern = fused_split<3, 4, true>;
+            CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            kern<<<2 * cus, 1024, lds, 0>>>(p); }
         else        { if (P == 2) GOS(2, 4); else if (P == 3) GOS(3, 4); else if (P == 4) GOS(4, 4); else GOS(6, 4); }
         CHECK(hipGetLastError());
     };
-    if (mode == 5) p.mode = 5;                 // the checked run needs both roles at G = CUs: not available in this shape
+    if (mode >= 5) p.mode = mode;                 // the checked run needs both roles at G = CUs: not available in this shape
     CHECK(hipMemset(y, 0xFF, (size_t)T * R * 4));
     launch();
     CHECK(hipDeviceSynchronize());
@@ -459,7 +505,7 @@ int main(int argc, char** argv) {
     fflush(stdout);
 
     p.mode = mode;
-    if (mode) printf("PROBE mode %d (%s): results are not checked\n", mode, mode == 1 ? "producers only" : mode == 2 ? "consumers only" : mode == 5 ? "phase 2 alone: two consumer workgroups per CU, products from a ring far larger than the caches" : "both roles, no flow control");
+    if (mode) printf("PROBE mode %d (%s): results are not checked\n", mode, mode == 1 ? "producers only" : mode == 2 ? "consumers only" : mode == 5 ? "phase 2 alone: two consumer workgroups per CU, products from a ring far larger than the caches" : mode == 6 ? "phase 2 alone, products and deltas TILE-major (a tile's runs contiguous)" : "both roles, no flow control");
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     float best = 1e9f, sum = 0;
     for (int r = 0; r < reps; ++r) {

@@ -6,10 +6,9 @@ mkdir -p gpurun_out
 : > $out
 run() { echo "== $*" >> $out; timeout -k 10 90 tools/fused_bench "$@" >> $out 2>&1 || { echo "FAILED rc=$? : $*" >> $out; return 1; }; }
 # W R D H P E reps mode
-run 16384 9792 2 1 2 4 5 5 &&
 run 16384 9792 2 1 3 4 5 5 &&
-run 16384 9792 2 1 4 4 5 5 &&
-run 16384 9792 2 1 6 4 5 5 &&
-run 16384 9792 2 1 3 8 5 5 &&
-run 16384 9792 2 1 4 8 5 5 
+run 16384 9792 2 1 3 4 5 8 &&
+run 16384 9792 2 1 3 4 5 2 &&
+run 16384 9792 2 1 3 4 5 3 &&
+run 16384 9792 2 1 3 4 5 0
 grep -v "^rows diff\|^registration" $out

@@ -1275,6 +1275,9 @@ __device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_in
     __syncthreads();
 }
 
+#ifndef SPMV_STREAM_DEPTH
+#define SPMV_STREAM_DEPTH 2
+#endif
 #ifndef SPMV_STREAM_SEGS
 #define SPMV_STREAM_SEGS 3      // segments per pass: 2 / 3 / 4 measured 492 / 482 / 483 us on C5, 47.9 / 48.7 / 51.9 on C2, 41.6 / 42.4 / 44.2 on C4
 #endif
@@ -1308,6 +1311,7 @@ __device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int 
     __syncthreads();
 
     constexpr int kSpan = 256;             // slots per pass: four per lane
+    constexpr int kDepth = SPMV_STREAM_DEPTH;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     constexpr int kWaves = kReduceBlock / 64;
@@ -1404,17 +1408,21 @@ __device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int 
             }
         };
 
-        Pass a, b;
-        build(a);
-        issue_loads(a);
-        while (a.valid) {
-            build(b);
-            issue_loads(b);
-            process(a);
-            if (!b.valid) break;
-            build(a);
-            issue_loads(a);
-            process(b);
+        // kDepth passes in flight, pass i of the stream in slot i mod kDepth; every slot always holds issued loads
+        Pass ps[kDepth];
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {
+            build(ps[u]);
+            issue_loads(ps[u]);
+        }
+        for (bool more = true; more;) {
+#pragma unroll
+            for (int u = 0; u < kDepth; ++u) {
+                if (!ps[u].valid) { more = false; break; }
+                process(ps[u]);
+                build(ps[u]);
+                issue_loads(ps[u]);
+            }
         }
     }
     __syncthreads();

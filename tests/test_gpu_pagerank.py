@@ -611,3 +611,18 @@ def test_two_matrices_over_one_row_pointer_array_keep_their_own_dangling_masks(g
         compare(gpu.pagerank(A2, cfg).ranks, want2)
     gpu.csr_destroy(A1)
     gpu.csr_destroy(A2)
+
+
+def test_spmv_num_gpus_on_a_box_with_fewer_devices_still_returns_ranks(gpu, oracle, monkeypatch):
+    """`SPMV_NUM_GPUS=8 ./existing_binary` on a machine with one device: the sharded run cannot start
+    and returns nothing; pagerank() must not pass that on — the reference's pagerank() always hands back an allocated
+    ranks array (include/spmv/pagerank.h:29-36) and its callers index it unchecked."""
+    n = 5000
+    rp, ci, va = graph(gpu, n, 6, 3, dangling=(2, 4000))
+    A = upload(gpu, rp, ci, va, n)
+    monkeypatch.setenv("SPMV_NUM_GPUS", "8")
+    r = gpu.pagerank(A, gpu.PageRankConfig(0.85, 1e-6, 100))
+    monkeypatch.delenv("SPMV_NUM_GPUS")
+    assert r.ranks is not None and len(r.ranks) == n
+    assert_parity(gpu, oracle, A, rp, ci, va, n, r)
+    gpu.csr_destroy(A)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# same-box A/B of engine knobs on C5 / C2: every configuration three times, interleaved; prints all and the medians
+# usage: tools/ab_sweep.sh "<ENV=VAL ...>" "<ENV=VAL ...>" ...   (an empty string = defaults); WHICH="c5only c2only" by default
+cd "$(dirname "$0")/.."
+out=gpurun_out/ab_sweep.txt
+mkdir -p gpurun_out; : > $out
+WHICH=${WHICH:-"c5only c2only"}
+for round in 1 2 3; do
+  i=0
+  for cfg in "$@"; do
+    i=$((i + 1))
+    env $cfg python tools/quick_bench.py $WHICH 2>&1 | grep "kernel=" | sed "s/^/cfg$i round$round [$cfg] /" >> $out
+  done
+done
+python3 - "$out" <<'PY'
+import collections, re, statistics, sys
+acc = collections.defaultdict(list)
+for line in open(sys.argv[1]):
+    m = re.match(r"(cfg\d+) round\d+ \[(.*?)\] (\S+ \S+ \S+ \S+).*avg=\s*([\d.]+)us", line)
+    if m: acc[(m.group(1), m.group(2), m.group(3).strip())].append(float(m.group(4)))
+for (cfg, env, name), v in sorted(acc.items()):
+    print(f"{cfg} [{env or 'defaults'}] {name:22s} median {statistics.median(v):8.1f} us   all {v}")
+PY

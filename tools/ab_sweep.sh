@@ -16,8 +16,8 @@ python3 - "$out" <<'PY'
 import collections, re, statistics, sys
 acc = collections.defaultdict(list)
 for line in open(sys.argv[1]):
-    m = re.match(r"(cfg\d+) round\d+ \[(.*?)\] (\S+ \S+ \S+ \S+).*avg=\s*([\d.]+)us", line)
-    if m: acc[(m.group(1), m.group(2), m.group(3).strip())].append(float(m.group(4)))
+    m = re.match(r"(cfg\d+) round\d+ \[(.*?)\] (.*?)\s+kernel=(\d+).*avg=\s*([\d.]+)us", line)
+    if m: acc[(m.group(1), m.group(2), m.group(3).strip() + " k" + m.group(4))].append(float(m.group(5)))
 for (cfg, env, name), v in sorted(acc.items()):
     print(f"{cfg} [{env or 'defaults'}] {name:22s} median {statistics.median(v):8.1f} us   all {v}")
 PY

@@ -41,6 +41,7 @@ struct Params {
     unsigned* ctl;                              // [0..7] registration per XCC, [8] abort, [9] spin statistics
     unsigned* ready; unsigned* done;            // per team
     int items_per_team, ready_per_team;
+    int batch;                                  // items a consumer wavefront takes per batch (its done signals go out at the batch's end)
     int mode;                                   // 0 normal, 1 producers only, 2 consumers only (timing probes: results meaningless)
 };
 
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(1024, 8) void fused_split(Params p) {
     unsigned polls = 0;
     constexpr int kSpan = 64 * E;                 // slots per pass
     constexpr int kGroups = E / 4;                // 16-byte product loads per lane and pass
-    constexpr int kBatch = 8;                     // items per batch: bounds how long a done signal waits
+    const int kBatch = p.batch;                   // items per batch: bounds how long a done signal waits
     for (int gi = 0; gi < p.NG; ++gi) {
         const int t = gi * G + member;
         const bool active = t < p.T;
@@ -391,6 +392,7 @@ int main(int argc, char** argv) {
     const int E = argc > 6 ? atoi(argv[6]) : 4;
     const int reps = argc > 7 ? atoi(argv[7]) : 5;
     const int mode = argc > 8 ? atoi(argv[8]) : 0;
+    const int batch = argc > 9 ? atoi(argv[9]) : 8;
     const long long rows = 10000000, cols = 10000000, entries = 160000000;
     const int S = (int)((cols + W - 1) / W), T = (int)((rows + R - 1) / R);
     const int L = (int)(entries / ((long long)S * T));         // mean run length
@@ -473,7 +475,7 @@ int main(int argc, char** argv) {
     p.a_val = a_val; p.a_lcol = a_lcol; p.a_drow = a_drow; p.cells_t = d_cells_t; p.items = d_items; p.x = x; p.y = y; p.ring = ring;
     p.cells_tm = d_cells_tm; p.a_drow_tm = a_drow_tm;
     p.ctl = flags; p.done = flags + ctl_words; p.ready = flags + ctl_words + (size_t)items_per_team * kDoneStride;
-    p.items_per_team = items_per_team; p.ready_per_team = ready_per_team; p.mode = 0;
+    p.items_per_team = items_per_team; p.ready_per_team = ready_per_team; p.mode = 0; p.batch = batch;
     const size_t lds = std::max((size_t)W * 4, (size_t)R * 8);
 
     auto launch = [&]() {

@@ -82,7 +82,7 @@ def supervise(child_cmd=None):
     rank = int(os.environ.get("RANK", "0"))
     env = dict(os.environ, SPMV_BENCH_CHILD="1")
     child = subprocess.Popen(child_cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                             stdout=subprocess.PIPE, env=env, start_new_session=True)
+                             stdout=subprocess.PIPE, env=env)       # same process group: whoever ends the job ends the child too
     state = {"line": None, "measured_at": None, "final": False}
 
     def reader():
@@ -106,9 +106,10 @@ def supervise(child_cmd=None):
 
     def finish(reason):
         if child.poll() is None:
+            child.kill()
             try:
-                os.killpg(child.pid, signal.SIGKILL)
-            except OSError:
+                child.wait(timeout=10)
+            except Exception:                           # noqa: BLE001
                 pass
         thread.join(timeout=5)
         obj = state["line"]

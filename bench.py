@@ -658,6 +658,21 @@ def parity_report(spmv, wl, seed):
     return out
 
 
+def host_core_share():
+    """How many host cores this job may really use: the cgroup's CPU quota when there is one (a GPU box of the pool shows 256
+    CPUs and grants 16), else the affinity mask; at most 64 threads (the matrix is 1.3 GB: past that the memory system, not
+    the cores, bounds a CSR SpMV)."""
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            share = max(1, int(int(quota) / int(period)))
+            return min(share, visible, 64), "the cgroup CPU quota (%d of %d visible CPUs)" % (share, visible)
+    except Exception:                                   # noqa: BLE001 - cgroup v1 or no cgroup: fall through
+        pass
+    return min(visible, 64), "the affinity mask (%d CPUs), capped at 64" % visible
+
+
 def cpu_baseline(spmv, row_ptrs, cols, vals, n, nnz):
     """The reference's CPU path (src/spmv_cpu.cpp:6-16) on the SAME matrix, one host thread:
     oracle/_ref/ref_cpu (the reference's own sources, kind "reference") when it was shipped,
@@ -687,7 +702,7 @@ def cpu_baseline(spmv, row_ptrs, cols, vals, n, nnz):
               "host_cpus_visible": os.cpu_count()}
     # (ii) the same loop over OpenMP static row blocks — the reference has no OpenMP,
     # so this row is a port; threads = the box's CPU share for one GPU (16) or fewer
-    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1))
+    threads, share_source = host_core_share()
     y1 = oracle.spmv_csr_parallel(rp, ci, va, x, threads)
     best_par = 1e30
     for _ in range(reps):
@@ -696,7 +711,7 @@ def cpu_baseline(spmv, row_ptrs, cols, vals, n, nnz):
         best_par = min(best_par, time.perf_counter() - t0)
     parallel = {"value": round(b / best_par / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
                 "gflops": round(2.0 * nnz / best_par / 1e9, 3), "seconds_per_spmv": round(best_par, 4),
-                "sample": "same matrix, OpenMP static row blocks, best of %d after 1 warm-up" % reps,
+                "sample": "same matrix, OpenMP static row blocks, best of %d after 1 warm-up; threads = %s" % (reps, share_source),
                 "checksum": float(np.float64(y1.sum(dtype=np.float64)))}
     return single, parallel
 

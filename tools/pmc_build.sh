@@ -21,7 +21,7 @@ out = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "pmc_build")
 for path in glob.glob(os.path.join(out, "*", "*_counter_collection.csv")):
     for row in csv.DictReader(open(path)):
         k = re.sub(r"\(anonymous namespace\)::|spmv::detail::|void ", "", row["Kernel_Name"]).split("(")[0]
-        if "batch_sort" in k or "cell_place" in k or "max_row" in k:
+        if "batch_" in k or "cell_place" in k or "max_row" in k:
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     print(k)

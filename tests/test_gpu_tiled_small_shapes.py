@@ -25,3 +25,9 @@ def test_small_and_awkward_shapes_through_the_tiled_engine(gpu, stream):
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "tiled small shapes:" in out.stdout
     assert "reference fixtures through the tiled engine: 13 cases" in out.stdout
+    # cells with hand-picked slot counts (every boundary case of phase 2's passes), shape forced to 4096 x 1024
+    env.update(SPMV_TILED_STRIP="4096", SPMV_TILED_TILE="1024")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tiled_small_shapes_worker.py"), "patterns"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "run-length patterns:" in out.stdout

@@ -121,6 +121,50 @@ def main():
     golden_fixtures()
 
 
+def run_length_patterns():
+    """Cells (strip x tile) whose slot counts are chosen one by one, so that phase 2's slot stream meets every boundary
+    case: runs of 0 / 1 / 3 / 4 / 5 slots, runs just under / at / over one pass (252 / 256 / 260) and two (511 / 512 / 513), long
+    trains of empty runs, runs longer than a tile has rows, > 64 runs per wavefront (more than one window of run records:
+    1100 strips = 69 runs per wavefront) — against the oracle, through VECTOR_CSR and MERGE_PATH with use_texture."""
+    import scipy.sparse as sp
+    strips, tiles = 1100, 2
+    w, r = 4096, 1024                                  # forced by the test's environment (SPMV_TILED_STRIP / SPMV_TILED_TILE)
+    assert os.environ.get("SPMV_TILED_STRIP") == "4096" and os.environ.get("SPMV_TILED_TILE") == "1024"
+    rows, cols = tiles * r, strips * w
+    base = [0, 0, 3, 4, 5, 252, 256, 260, 0, 1, 511, 512, 513, 64, 64, 64, 64, 7] + [0] * 53 + [1000, 2, 0, 0, 1500, 8, 248, 12]
+    rng = np.random.default_rng(99)
+    rr, cc = [], []
+    for t in range(tiles):
+        pattern = np.array([base[(s + 11 * t) % len(base)] for s in range(strips)])
+        pattern[rng.integers(0, strips, size=40)] = rng.integers(1, 700, size=40)     # and some arbitrary ones
+        for s in np.nonzero(pattern)[0]:
+            n = int(pattern[s])
+            i = np.arange(n)
+            rr.append(t * r + (i * 7 + s) % r)                     # n <= r: distinct rows; beyond: the column moves on
+            cc.append(s * w + ((i // r) * 5 + (i * 13) % 5 + (s % 3)) % w)
+    rr, cc = np.concatenate(rr), np.concatenate(cc)
+    keys = np.unique(rr.astype(np.int64) * cols + cc)              # distinct (row, column) pairs, row-major
+    rr, cc = (keys // cols).astype(np.int64), (keys % cols).astype(np.int32)
+    va = rng.uniform(-1, 1, size=keys.size).astype(np.float32)
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rr, minlength=rows))]).astype(np.int32)
+    x = rng.uniform(-1, 1, size=cols).astype(np.float32)
+    want = oracle.spmv_csr(rp, cc, va, x)
+    A = spmv.csr_from_arrays(rows, cols, rp, cc, va)
+    assert spmv.csr_to_gpu(A) == 0
+    d_x, d_y = spmv.CudaBuffer(cols), spmv.CudaBuffer(rows)
+    d_x.copyFromHost(x, cols)
+    for kernel in (1, 2):
+        for _ in range(2):
+            res = spmv.spmv_csr(A, d_x, d_y, spmv.SpMVConfig(kernel_type=kernel, use_texture=True), cols)
+            assert res.error_code == 0
+            err = reorder_err(rp, cc, va, x, want, d_y.copyToHost(rows))
+            assert err <= 1e-5, (kernel, err)
+    info = spmv.csr_tiled_info(A)
+    assert info and info["num_strips"] == strips and info["tile_rows"] == r, info
+    spmv.csr_destroy(A)
+    print("run-length patterns: %d entries in %d strips x %d tiles" % (keys.size, strips, tiles))
+
+
 def golden_fixtures():
     """The 13 inputs of tests/golden/ref_cases.npz through the tiled engine (CSR as VECTOR_CSR and MERGE_PATH with
     use_texture, the ELL slabs with use_texture), against the y the REFERENCE's own spmv_cpu_csr / spmv_cpu_ell
@@ -160,4 +204,8 @@ def golden_fixtures():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["patterns"]:
+        spmv.require_gpu()
+        run_length_patterns()
+    else:
+        main()

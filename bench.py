@@ -114,7 +114,7 @@ def supervise(child_cmd=None):
         thread.join(timeout=5)
         obj = state["line"]
         if obj is not None and rank == 0:
-            if obj.pop("provisional", False) or reason:
+            if obj.pop("provisional", False):          # (a final line is complete whatever ends the child afterwards)
                 obj["incomplete"] = reason or "the run ended before its last extra (exit code %s)" % child.returncode
             sys.stdout.write(json.dumps(obj) + "\n")
             sys.stdout.flush()
@@ -125,10 +125,16 @@ def supervise(child_cmd=None):
     for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
         signal.signal(sig, lambda number, frame: finish("signal %d while the extras were running" % number))
     deadline = float(os.environ.get("SPMV_BENCH_EXTRAS_DEADLINE", "1500"))
+    final_at = None
     while child.poll() is None:
         time.sleep(0.2)
-        if state["measured_at"] is not None and not state["final"] and time.time() - state["measured_at"] > deadline:
+        now = time.time()
+        if state["final"] and final_at is None:
+            final_at = now
+        if state["measured_at"] is not None and not state["final"] and now - state["measured_at"] > deadline:
             finish("the extras did not finish within %.0f s of the measurement: child killed" % deadline)
+        if final_at is not None and now - final_at > deadline:       # opt-in trials or the teardown hang behind a complete line
+            finish(None)
     finish(None)
 
 

@@ -82,3 +82,14 @@ def test_other_ranks_exit_zero_once_they_have_measured(tmp_path):
         os.abort()
     """, env={"RANK": "1"})
     assert out.returncode == 0 and out.stdout.strip() == ""
+
+
+def test_a_hang_behind_the_final_line_is_cut_off_and_the_line_is_complete(tmp_path):
+    out = run_supervisor(tmp_path, f"""
+        import json, sys, time
+        print(json.dumps({LINE!r}), flush=True)
+        time.sleep(600)
+    """, env={"SPMV_BENCH_EXTRAS_DEADLINE": "1"})
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip())
+    assert got["value"] == 1.0 and "incomplete" not in got

@@ -108,7 +108,9 @@ constexpr int kBuildRowCache = 1024;        // row offsets of the batch kept in 
 constexpr int kBuildLdsSmall = 70 * 1024;   // dynamic LDS of a builder workgroup (two per CU, next to 8 KiB static) ...
 constexpr int kBuildLdsLarge = 148 * 1024;  // ... or one per CU when the strips are many
 constexpr int kBuildBinWords = 4;           // LDS ints per strip: start, cursor, markers, first|last
-constexpr int kBuildEntryBytes = 13;        // LDS bytes per entry: key 4, source index 4, bin 2, row mark 2, markers 1
+constexpr int kBuildEntryBytes = 11;        // LDS bytes per entry: key 4, source index 4 (the row marks, 2, live there first), bin 2, markers 1
+// per strip, next to the four bin words: one byte per wavefront of the ranking workgroup (sixteen): the stable binning's counters
+constexpr int kBuildWaveCountBytes = kBuildBlock / 64;
 constexpr int kMaxBuildStrips = 3072;
 
 // where the entries come from.  offset(row) = index of the row's first entry in a virtual row-major
@@ -140,6 +142,7 @@ struct EllSource {
 struct BuildShape {
     int num_rows, num_tiles, num_strips, strip_shift, tile_rows, long_row;
     int any_long;               // some row is longer than long_row (then every entry's row length is checked)
+    int stable_bins;            // the ranking pass may bin stably (no ranking loop); 0: always rank by comparison (SPMV_TILED_RANK=plain)
     long long quota;            // entries per batch before the next one starts
 };
 
@@ -259,11 +262,17 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
     int* bin_cursor = build_lds + S;            // [S] histogram, then fill cursor (= bin end once filled)
     int* bin_escapes = build_lds + 2 * S;       // [S] skip markers needed in front of the bin's non-first slots
     int* bin_ends = build_lds + 3 * S;          // [S] first lrow << 16 | last lrow
-    unsigned int* keys = reinterpret_cast<unsigned int*>(build_lds + kBuildBinWords * S);    // lrow << 16 | lcol
+    // per wavefront and strip one BYTE (four strips to a word): how many of the wavefront's entries fall into the strip,
+    // then where in the bin its next one goes (stable binning, below)
+    const int S4 = (S + 3) / 4;                 // words per wavefront
+    unsigned int* wave_count = reinterpret_cast<unsigned int*>(build_lds + kBuildBinWords * S);
+    unsigned int* keys = wave_count + (kBuildBlock / 64) * S4;    // lrow << 16 | lcol
     unsigned int* source = keys + capacity;     // index of the slot's entry, relative to the batch's first entry
     unsigned short* bin_of = reinterpret_cast<unsigned short*>(source + capacity);
-    unsigned short* row_mark = bin_of + capacity;          // entry index -> row (relative), after a max-scan
-    unsigned char* markers = reinterpret_cast<unsigned char*>(row_mark + capacity);
+    unsigned short* row_mark = reinterpret_cast<unsigned short*>(source);   // entry index -> row (relative), after a max-scan; read
+                                                                            // for the last time before `source` is first written
+    unsigned char* markers = reinterpret_cast<unsigned char*>(bin_of + capacity);
+    __shared__ int s_plain;                     // this batch ranks its bins by comparison (the stable binning does not apply)
 
     const int tile = batch_tile[batch];
     const int row0 = batch_row[batch];
@@ -278,10 +287,18 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
     const bool fast = entry1 - entry0 <= capacity;
     const int span = fast ? static_cast<int>(entry1 - entry0) : 0;
     // the fast path's column loads are issued first: they travel while the rows are being marked and scanned
+    // Every wavefront takes a CONTIGUOUS share of the batch's entries, 64 at a time in source order (so that the stable
+    // binning below can rely on "earlier wavefront, earlier instruction, lower lane = earlier entry").
+    const int wave_id = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+    const int per_wave = ((span + kBuildBlock / 64 - 1) / (kBuildBlock / 64) + 63) / 64 * 64;      // <= 64 * kBuildPerThread
+    auto entry_of = [&](int u) {                       // index of this thread's u-th entry, or `span` (none)
+        const int within = u * 64 + lane_id;
+        return within < per_wave ? min(wave_id * per_wave + within, span) : span;
+    };
     int my_col[kBuildPerThread];
 #pragma unroll
     for (int u = 0; u < kBuildPerThread; ++u) {
-        const int idx = threadIdx.x + u * kBuildBlock;
+        const int idx = entry_of(u);
         my_col[u] = idx < span ? src.col(entry0 + idx) : -1;
     }
 
@@ -290,7 +307,11 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
         bin_escapes[i] = 0;
         bin_ends[i] = 0;
     }
-    if (threadIdx.x == 0) s_overflow = 0;
+    for (int i = threadIdx.x; i < (kBuildBlock / 64) * S4; i += kBuildBlock) wave_count[i] = 0;
+    if (threadIdx.x == 0) {
+        s_overflow = 0;
+        s_plain = fast && sh.stable_bins ? 0 : 1;
+    }
     const bool rows_cached = Src::kSearchRows && !fast && row1 - row0 <= kBuildRowCache;
     if (rows_cached) {
         for (int r = row0 + threadIdx.x; r <= row1; r += kBuildBlock) s_row_cache[r - row0] = static_cast<int>(src.offset(r));
@@ -366,7 +387,7 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
     if (fast) {
 #pragma unroll
         for (int u = 0; u < kBuildPerThread; ++u) {
-            const int idx = threadIdx.x + u * kBuildBlock;
+            const int idx = entry_of(u);
             my_lrow[u] = 0;
             if (my_col[u] >= 0) {
                 const long long j = entry0 + idx;
@@ -375,7 +396,10 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
                     my_col[u] = -1;
                 } else {
                     my_lrow[u] = row - tile_first;
-                    atomicAdd(&bin_cursor[my_col[u] >> sh.strip_shift], 1);
+                    const int strip = my_col[u] >> sh.strip_shift;
+                    atomicAdd(&bin_cursor[strip], 1);
+                    // (bytes may run over into their neighbours when a bin holds more than 255: such a batch ranks by comparison)
+                    atomicAdd(&wave_count[wave_id * S4 + (strip >> 2)], 1u << (8 * (strip & 3)));
                 }
             }
         }
@@ -395,16 +419,44 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
         int sum = 0;
         for (int i = lo; i < hi; ++i) sum += bin_cursor[i];
         int run = block_exclusive_scan<false>(sum, s_partial, &total);
+        bool big = false;
         for (int i = lo; i < hi; ++i) {
             const int n = bin_cursor[i];
             bin_start[i] = run;
             bin_cursor[i] = run;
             run += n;
+            big = big || n > 255;
         }
+        if (big) s_plain = 1;           // a byte counter per wavefront and strip cannot hold this bin
         if (threadIdx.x == 0 && total > capacity) s_overflow = 1;
     }
     __syncthreads();
     if (s_overflow) return;          // cannot happen (the batch quota bounds the count); never write past LDS
+
+    // STABLE BINNING (the usual case).  The entries of a batch arrive in (row, column) order — the order a bin must end up
+    // in.  So instead of filling the bins in whatever order the atomics land and ranking every entry against its whole
+    // bin afterwards (a loop as long as the longest bin of the wavefront: 2.4 of the kernel's 4.3 vector instructions per
+    // entry, profiles/r03_build_counters.txt), every entry is sent straight to its final place: the count of its strip
+    // in earlier wavefronts (the byte counters, turned into running offsets here) + its turn among its own wavefront's
+    // entries (a returning LDS add; a wavefront issues its entries in source order).  The order in which ONE instruction's
+    // lanes get their turn at the same counter is the hardware's; the bins are therefore checked afterwards (each slot
+    // against its predecessor) and a batch that is out of order — also: rows whose columns are not ascending — falls back to
+    // ranking by comparison.  Either way the layout is the same function of the matrix.
+    const bool try_stable = s_plain == 0;
+    if (try_stable) {
+        unsigned char* bytes = reinterpret_cast<unsigned char*>(wave_count);
+        for (int b = threadIdx.x; b < S; b += kBuildBlock) {
+            int running = 0;
+#pragma unroll
+            for (int w = 0; w < kBuildBlock / 64; ++w) {
+                const int at = (w * S4 + (b >> 2)) * 4 + (b & 3);
+                const int mine = bytes[at];
+                bytes[at] = static_cast<unsigned char>(running);
+                running += mine;
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- fill the bins (order inside a bin is arbitrary here; the ranking below fixes it)
     auto put = [&](int c, int lrow, unsigned int from) {
@@ -414,10 +466,24 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
         source[u] = from;
         bin_of[u] = static_cast<unsigned short>(strip);
     };
-    if (fast) {
+    if (try_stable) {
 #pragma unroll
         for (int u = 0; u < kBuildPerThread; ++u) {
-            if (my_col[u] >= 0) put(my_col[u], my_lrow[u], threadIdx.x + u * kBuildBlock);
+            if (my_col[u] >= 0) {
+                const int strip = my_col[u] >> sh.strip_shift;
+                const int shift = 8 * (strip & 3);
+                const unsigned int before = atomicAdd(&wave_count[wave_id * S4 + (strip >> 2)], 1u << shift);
+                const int slot = bin_start[strip] + static_cast<int>((before >> shift) & 0xFF);
+                atomicAdd(&bin_cursor[strip], 1);          // (ends as the bin's end, like the unordered fill leaves it)
+                keys[slot] = (static_cast<unsigned int>(my_lrow[u]) << 16) | static_cast<unsigned int>(my_col[u] - (strip << sh.strip_shift));
+                source[slot] = static_cast<unsigned int>(entry_of(u));
+                bin_of[slot] = static_cast<unsigned short>(strip);
+            }
+        }
+    } else if (fast) {
+#pragma unroll
+        for (int u = 0; u < kBuildPerThread; ++u) {
+            if (my_col[u] >= 0) put(my_col[u], my_lrow[u], entry_of(u));
         }
     } else {
         for_each_entry([&](long long j, int c) {
@@ -431,6 +497,20 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
     // ---- rank inside the bin = number of slots ordered before this one; the largest key among them is the
     //      predecessor's.  Order: (row, column).  A row that stores one column twice (legal CSR) ties: such
     //      slots are ordered by their source index (the CSR order), found in a second, rare, loop.
+    if (try_stable) {                     // is every slot behind its bin's previous one?  (row, column), twins by source index
+        bool ordered = true;
+#pragma unroll
+        for (int k = 0; k < kBuildPerThread; ++k) {
+            const int u = threadIdx.x + k * kBuildBlock;
+            if (u < total && u > bin_start[bin_of[u]]) {
+                const unsigned int pred = keys[u - 1], mine = keys[u];
+                ordered = ordered && (pred < mine || (pred == mine && source[u - 1] < source[u]));
+            }
+        }
+        if (!ordered) s_plain = 1;
+        __syncthreads();
+    }
+    const bool stable = s_plain == 0;     // (the same for every thread: read after a barrier)
     int my_rank[kBuildPerThread], my_need[kBuildPerThread], my_delta[kBuildPerThread];
 #pragma unroll
     for (int k = 0; k < kBuildPerThread; ++k) {
@@ -442,21 +522,27 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
             const int bin = bin_of[u];
             const int lo = bin_start[bin], hi = bin_cursor[bin];
             const unsigned int mine = keys[u];
-            int rank = 0, ties = 0;
+            int rank = 0;
             unsigned int pred = 0;
-            for (int v = lo; v < hi; ++v) {
-                const unsigned int key = keys[v];
-                const bool less = key < mine;
-                rank += less;
-                pred = less ? max(pred, key) : pred;
-                ties += key == mine;
-            }
-            if (ties > 1) {               // duplicate (row, column): order the twins by source index
-                const unsigned int me = source[u];
+            if (stable) {                 // the slot IS the rank
+                rank = u - lo;
+                pred = rank > 0 ? keys[u - 1] : 0u;
+            } else {
+                int ties = 0;
                 for (int v = lo; v < hi; ++v) {
-                    if (keys[v] == mine && source[v] < me) {
-                        ++rank;
-                        pred = mine;
+                    const unsigned int key = keys[v];
+                    const bool less = key < mine;
+                    rank += less;
+                    pred = less ? max(pred, key) : pred;
+                    ties += key == mine;
+                }
+                if (ties > 1) {           // duplicate (row, column): order the twins by source index
+                    const unsigned int me = source[u];
+                    for (int v = lo; v < hi; ++v) {
+                        if (keys[v] == mine && source[v] < me) {
+                            ++rank;
+                            pred = mine;
+                        }
                     }
                 }
             }
@@ -1837,7 +1923,7 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
 
     // ---- batch geometry: how many entries a builder workgroup can hold in LDS
     const int lds_bytes = S <= 1024 ? kBuildLdsSmall : kBuildLdsLarge;
-    int capacity = (lds_bytes - kBuildBinWords * 4 * S) / kBuildEntryBytes / 64 * 64;
+    int capacity = (lds_bytes - kBuildBinWords * 4 * S - kBuildWaveCountBytes * ((S + 3) / 4 * 4)) / kBuildEntryBytes / 64 * 64;
     if (capacity < 512) return cleanup(hipErrorInvalidValue);
     capacity = std::min(capacity, kBuildMaxCapacity);        // what a workgroup's threads keep in registers
     max_row_kernel<<<std::min(2048, (plan->num_rows + kBlock - 1) / kBlock), kBlock, 0, s>>>(dev_src, plan->num_rows, d_small);
@@ -1857,6 +1943,8 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     sh.long_row = plan->long_row;
     sh.quota = std::max(64, capacity - std::min(longest, plan->long_row));
     sh.any_long = longest > plan->long_row ? 1 : 0;
+    sh.stable_bins = 1;
+    if (const char* env = std::getenv("SPMV_TILED_RANK")) sh.stable_bins = std::strcmp(env, "plain") != 0;
 
     tile_batches_kernel<<<(T + kBlock - 1) / kBlock, kBlock, 0, s>>>(dev_src, sh, tile_batch);
     // exclusive scan of the per-tile batch counts (one workgroup: T is at most a few hundred thousand)

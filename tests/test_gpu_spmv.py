@@ -450,6 +450,57 @@ def test_both_placing_passes_build_the_same_plan(gpu, monkeypatch):
         A.close()
 
 
+def test_stable_binning_and_ranking_by_comparison_build_the_same_plan(gpu, oracle, monkeypatch):
+    """The builder's ranking pass sends every entry straight to its final place in its strip's bin (stable binning: the
+    entries of a batch arrive in (row, column) order) and falls back to ranking by comparison when a bin holds more than
+    255 entries or comes out unordered (rows whose columns are not ascending).  SPMV_TILED_RANK=plain forces the
+    comparison everywhere.  Same layout either way: equal checksums, bit-equal y — on a uniform matrix, a power-law one
+    (long rows: mixed batches), one with few strips and fat bins (> 255 entries per bin: the fallback inside the default
+    build), and one whose rows hold their columns in DESCENDING order (the order check must catch it)."""
+    wl = importlib.import_module("gpu-spmv_amd.workloads")
+
+    def descending_columns():
+        rp, ci, va = gpu.synth.uniform_csr(9, 0, 300_000, 500_000, 9)
+        ci = ci.reshape(-1, 9)[:, ::-1].copy().reshape(-1)              # every row back to front
+        va = va.reshape(-1, 9)[:, ::-1].copy().reshape(-1)
+        A = wl.DeviceCSR(300_000, 500_000, int(ci.size))
+        A.row_ptrs.copyFromHost(rp.astype(np.int32), rp.size)
+        A.col_indices.copyFromHost(ci.astype(np.int32), ci.size)
+        A.values.copyFromHost(va.astype(np.float32), va.size)
+        return A
+
+    for name, make, kernel in (("uniform", lambda: wl.uniform_csr_device(6, 500_000, 800_000, 10), 1),
+                               ("power_law", lambda: wl.power_law_csr_device(6, 400_000, 600_000), 2),
+                               ("fat_bins", lambda: wl.uniform_csr_device(6, 400_000, 70_000, 24), 1),
+                               ("descending", descending_columns, 1)):
+        A = make()
+        assert gpu.tiled_shape(A.rows, A.cols, A.nnz)[0], name
+        x = wl.vector_device(6, 1, A.cols)
+        y = gpu.CudaBuffer(A.rows)
+        cfg = gpu.SpMVConfig(kernel, 256, True)
+        seen = {}
+        for form in ("stable", "plain", "stable"):
+            monkeypatch.setenv("SPMV_TILED_RANK", form)
+            gpu.csr_invalidate_gpu_cache(A.handle)
+            assert gpu.spmv_csr(A.handle, x, y, cfg, A.cols).error_code == 0
+            sums = gpu.csr_tiled_checksum(A.handle)
+            assert sums is not None
+            bits = y.copyToHost(A.rows).view(np.uint32).copy()
+            if seen:
+                assert sums == seen["sums"], (name, form, sums, seen["sums"])
+                assert np.array_equal(bits, seen["bits"]), (name, form)
+            else:
+                seen = {"sums": sums, "bits": bits}
+        monkeypatch.delenv("SPMV_TILED_RANK")
+        if name == "descending":                # and the result is right, not just the same twice
+            rp, ci, va = A.to_host()
+            xh = x.copyToHost(A.cols)
+            assert reorder_err(rp, ci, va, xh, oracle.spmv_csr(rp, ci, va, xh), y.copyToHost(A.rows)) <= 1e-5
+        x.release()
+        y.release()
+        A.close()
+
+
 def test_tiled_engine_folds_column_uniform_values(gpu, oracle, monkeypatch):
     """Every stored entry of a column equal (a_ij = 1 / outdeg(j), adjacency matrices): the plan keeps one
     weight per column and streams no values; one differing entry, or SPMV_TILED_FOLD=0, keeps the value

@@ -444,14 +444,13 @@ void batch_rank_kernel(Src src, BuildShape sh, int num_batches, int capacity,
     // ranking by comparison.  Either way the layout is the same function of the matrix.
     const bool try_stable = s_plain == 0;
     if (try_stable) {
-        unsigned char* bytes = reinterpret_cast<unsigned char*>(wave_count);
-        for (int b = threadIdx.x; b < S; b += kBuildBlock) {
-            int running = 0;
+        // four strips at a time: the bytes of a word never carry into each other (every strip's total is <= 255 here)
+        for (int i = threadIdx.x; i < S4; i += kBuildBlock) {
+            unsigned int running = 0;
 #pragma unroll
             for (int w = 0; w < kBuildBlock / 64; ++w) {
-                const int at = (w * S4 + (b >> 2)) * 4 + (b & 3);
-                const int mine = bytes[at];
-                bytes[at] = static_cast<unsigned char>(running);
+                const unsigned int mine = wave_count[w * S4 + i];
+                wave_count[w * S4 + i] = running;
                 running += mine;
             }
         }

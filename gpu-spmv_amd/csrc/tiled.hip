@@ -147,16 +147,48 @@ struct BuildShape {
 };
 
 // longest row (capped by the caller): sizes the batches
+// one atomicMax per WORKGROUP: every wavefront adding its own to one address serialises 8 K atomics at the memory side (~80 us)
+__device__ __forceinline__ void publish_block_max(int best, int* __restrict__ out) {
+    __shared__ int s_best[kBlock / 64];
+    for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int all = s_best[0];
+        for (int w = 1; w < kBlock / 64; ++w) all = max(all, s_best[w]);
+        if (all > 0) atomicMax(out, all);
+    }
+}
+
 template <typename Src>
 __global__ __launch_bounds__(kBlock)
 void max_row_kernel(Src src, int num_rows, int* __restrict__ out) {
     int best = 0;
+    if constexpr (Src::kSearchRows) {
+        // CSR: four rows per thread and step — one 16-byte load of the row pointers + the one behind them (the pointer array
+        // is hipMalloc'd or a whole torch tensor in every caller; an unaligned base takes the plain loop below)
+        const int* rp = src.row_ptrs;
+        if ((reinterpret_cast<unsigned long long>(rp) & 15) == 0) {
+            const long long groups = num_rows / 4;
+            for (long long g = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; g < groups;
+                 g += static_cast<long long>(gridDim.x) * kBlock) {
+                const i32x4 v = *reinterpret_cast<const i32x4*>(rp + 4 * g);
+                const int next = rp[4 * g + 4];
+                best = max(max(best, v[1] - v[0]), max(max(v[2] - v[1], v[3] - v[2]), next - v[3]));
+            }
+            if (blockIdx.x == 0 && threadIdx.x < num_rows % 4) {
+                const int r = num_rows / 4 * 4 + threadIdx.x;
+                best = max(best, rp[r + 1] - rp[r]);
+            }
+            publish_block_max(best, out);
+            return;
+        }
+    }
     for (long long r = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; r < num_rows;
          r += static_cast<long long>(gridDim.x) * kBlock) {
         best = max(best, static_cast<int>(src.offset(static_cast<int>(r) + 1) - src.offset(static_cast<int>(r))));
     }
-    for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
-    if ((threadIdx.x & 63) == 0 && best > 0) atomicMax(out, best);
+    publish_block_max(best, out);
 }
 
 // batches per tile: a tile's rows are cut wherever the running entry count passes a multiple of quota
@@ -606,7 +638,7 @@ __global__ __launch_bounds__(kBuildBlock)
 void batch_place_kernel(Src src, BuildShape sh, int num_batches,
                         const int* __restrict__ batch_row, const int* __restrict__ batch_tile,
                         const uint2* __restrict__ groups,              // [batches * strips] GroupPlace
-                        const unsigned int* __restrict__ meta, const int* __restrict__ offs,
+                        const unsigned int* __restrict__ meta, const int2* __restrict__ cells_t,
                         float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
                         unsigned char* __restrict__ a_drow,
                         const unsigned char* __restrict__ todo /*null: every batch; else only the flagged ones*/) {
@@ -625,7 +657,8 @@ void batch_place_kernel(Src src, BuildShape sh, int num_batches,
     const long long entry0 = src.offset(row0), entry1 = src.offset(row1);
     for (int i = threadIdx.x; i < S; i += kBuildBlock) {
         place[i] = groups[static_cast<long long>(batch) * S + i];
-        cell_begin[i] = offs[static_cast<long long>(i) * sh.num_tiles + tile];
+        cell_begin[i] = cells_t[static_cast<long long>(tile) * S + i].x;     // (tile-major table: one contiguous read; the strip-major
+                                                                          //  offsets sit num_tiles ints apart: a line per strip)
     }
     __syncthreads();
     for (long long j0 = entry0 + threadIdx.x; j0 < entry1; j0 += 4 * kBuildBlock) {
@@ -683,7 +716,7 @@ __global__ __launch_bounds__(kBuildBlock, 8)
 void batch_place_staged_kernel(Src src, BuildShape sh, int num_batches, int capacity, int stage_slots,
                                const int* __restrict__ batch_row, const int* __restrict__ batch_tile,
                                const uint2* __restrict__ groups,              // [batches * strips] GroupPlace
-                               const unsigned int* __restrict__ meta, const int* __restrict__ offs,
+                               const unsigned int* __restrict__ meta, const int2* __restrict__ cells_t,
                                float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
                                unsigned char* __restrict__ a_drow, unsigned char* __restrict__ todo) {
     extern __shared__ int stage_lds[];
@@ -713,7 +746,8 @@ void batch_place_staged_kernel(Src src, BuildShape sh, int num_batches, int capa
     const int span = static_cast<int>(entry1 - entry0);
     for (int i = threadIdx.x; i < S; i += kBuildBlock) {
         place[i] = groups[static_cast<long long>(batch) * S + i];
-        cell_begin[i] = offs[static_cast<long long>(i) * sh.num_tiles + tile];
+        cell_begin[i] = cells_t[static_cast<long long>(tile) * S + i].x;     // (tile-major table: one contiguous read; the strip-major
+                                                                          //  offsets sit num_tiles ints apart: a line per strip)
         count[i] = 0;
     }
     __syncthreads();
@@ -814,9 +848,13 @@ void cell_place_kernel(int num_tiles, int num_strips, const int* __restrict__ ti
         const int tile = static_cast<int>(id / num_strips), strip = static_cast<int>(id % num_strips);
         int last = 0;
         unsigned int total = 0;
-        for (int b = tile_batch[tile]; b < tile_batch[tile + 1]; ++b) {
+        const int b_end = tile_batch[tile + 1];
+        uint2 ahead = make_uint2(0, 0);       // the next batch's record is fetched before this one's is rewritten (other addresses)
+        if (tile_batch[tile] < b_end) ahead = groups[static_cast<long long>(tile_batch[tile]) * num_strips + strip];
+        for (int b = tile_batch[tile]; b < b_end; ++b) {
             uint2* slot = groups + static_cast<long long>(b) * num_strips + strip;
-            const uint2 raw = *slot;
+            const uint2 raw = ahead;
+            if (b + 1 < b_end) ahead = groups[static_cast<long long>(b + 1) * num_strips + strip];
             GroupCount g;
             __builtin_memcpy(&g, &raw, sizeof(g));
             GroupPlace p;
@@ -835,8 +873,16 @@ void cell_place_kernel(int num_tiles, int num_strips, const int* __restrict__ ti
         }
         cell_slots[static_cast<long long>(strip) * num_tiles + tile] = static_cast<int>(total);
     }
+    // one atomic per workgroup (ten thousand wavefronts adding to one address serialise at the memory side)
+    __shared__ unsigned long long s_mine[kBlock / 64];
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(entry_total, mine);
+    if ((threadIdx.x & 63) == 0) s_mine[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long all = 0;
+        for (int w = 0; w < kBlock / 64; ++w) all += s_mine[w];
+        if (all) atomicAdd(entry_total, all);
+    }
 }
 
 // exclusive scan of round_up_4(in[i]) in three launches: block sums, scan of the sums, block scans
@@ -1925,7 +1971,7 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     int capacity = (lds_bytes - kBuildBinWords * 4 * S - kBuildWaveCountBytes * ((S + 3) / 4 * 4)) / kBuildEntryBytes / 64 * 64;
     if (capacity < 512) return cleanup(hipErrorInvalidValue);
     capacity = std::min(capacity, kBuildMaxCapacity);        // what a workgroup's threads keep in registers
-    max_row_kernel<<<std::min(2048, (plan->num_rows + kBlock - 1) / kBlock), kBlock, 0, s>>>(dev_src, plan->num_rows, d_small);
+    max_row_kernel<<<std::min(1024, (plan->num_rows + kBlock - 1) / kBlock), kBlock, 0, s>>>(dev_src, plan->num_rows, d_small);
     int longest = 0;
     e = hipMemcpyAsync(&longest, d_small, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -2008,6 +2054,10 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     if (e == hipSuccess) e = dev_alloc(&plan->a_drow, plan->nnz + 8);
     if (e == hipSuccess) e = dev_alloc(&plan->cells_t, 2 * cells);
     if (e != hipSuccess) return cleanup(e);
+    {   // the tile-major cell table first: the placing kernels read their tile's cell begins from it (one contiguous read)
+        const int grid = static_cast<int>(std::min<long long>((cells + kBlock) / kBlock, 4096));
+        cell_table_kernel<<<grid, kBlock, 0, s>>>(offs, S, T, reinterpret_cast<int2*>(plan->cells_t), strip_begin);
+    }
     if (plan->nnz > 0) {
         // staged placing pass (contiguous segments); the batches it cannot hold are flagged for the scattered one
         bool staged = true;
@@ -2025,19 +2075,15 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
             if (e != hipSuccess) return cleanup(e);
             if (staged) {
                 batch_place_staged_kernel<Src><<<xcd_grid(num_batches), kBuildBlock, stage_lds, s>>>(
-                    dev_src, sh, num_batches, capacity, stage_slots, batch_row, batch_tile, groups, meta, offs,
+                    dev_src, sh, num_batches, capacity, stage_slots, batch_row, batch_tile, groups, meta, reinterpret_cast<const int2*>(plan->cells_t),
                     plan->a_val, plan->a_lcol, plan->a_drow, todo);
             }
         }
         batch_place_kernel<Src><<<xcd_grid(num_batches), kBuildBlock, 12 * static_cast<size_t>(S), s>>>(
-            dev_src, sh, num_batches, batch_row, batch_tile, groups, meta, offs, plan->a_val, plan->a_lcol, plan->a_drow,
+            dev_src, sh, num_batches, batch_row, batch_tile, groups, meta, reinterpret_cast<const int2*>(plan->cells_t), plan->a_val, plan->a_lcol, plan->a_drow,
             staged ? todo : nullptr);
         cell_padding_kernel<<<static_cast<int>(std::min<long long>((cells + kBlock - 1) / kBlock, 4096)), kBlock, 0, s>>>(
             cell_slots, offs, cells, plan->a_val, plan->a_lcol, plan->a_drow);
-    }
-    {
-        const int grid = static_cast<int>(std::min<long long>((cells + kBlock) / kBlock, 4096));
-        cell_table_kernel<<<grid, kBlock, 0, s>>>(offs, S, T, reinterpret_cast<int2*>(plan->cells_t), strip_begin);
     }
     e = hipGetLastError();
     host_strip->assign(S + 1, 0);

@@ -99,7 +99,7 @@ __device__ __forceinline__ int xcd_contiguous(int block, int count) {
     const int which = (block % kXcds) * per_xcd + block / kXcds;
     return block / kXcds < per_xcd && which < count ? which : -1;
 }
-__host__ inline int xcd_grid(int count) { return (count + kXcds - 1) / kXcds * kXcds; }
+__host__ __device__ inline int xcd_grid(int count) { return (count + kXcds - 1) / kXcds * kXcds; }
 
 // ------------------------------------------------------------------ plan building ----
 constexpr int kSkip = 255;                  // row-delta byte: advance 255 rows, no entry
@@ -641,14 +641,18 @@ void batch_place_kernel(Src src, BuildShape sh, int num_batches,
                         const unsigned int* __restrict__ meta, const int2* __restrict__ cells_t,
                         float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
                         unsigned char* __restrict__ a_drow,
-                        const unsigned char* __restrict__ todo /*null: every batch; else only the flagged ones*/) {
+                        const int* __restrict__ todo /*null: every batch; else [0] = how many, [1 ...] = which (left by the staged pass)*/) {
     extern __shared__ int place_lds[];
-    const int batch = xcd_contiguous(blockIdx.x, num_batches);
-    if (batch < 0) return;
-    if (todo && !todo[batch]) return;
     const int S = sh.num_strips;
     uint2* place = reinterpret_cast<uint2*>(place_lds);
     int* cell_begin = place_lds + 2 * S;
+    // behind the staged pass only the batches it listed are left (usually none): a fixed grid walks the list — a workgroup
+    // per batch just to find out that there is nothing to do cost ~40 us of launches on C5
+    const int work = todo ? todo[0] : xcd_grid(num_batches);
+    for (int position = blockIdx.x; position < work; position += gridDim.x) {
+    const int batch = todo ? todo[1 + position] : xcd_contiguous(position, num_batches);
+    if (batch < 0) continue;
+    __syncthreads();                           // the previous batch's LDS records are no longer read
     const int tile = batch_tile[batch];
     const int row0 = batch_row[batch];
     const long long tile_end = min(static_cast<long long>(tile + 1) * sh.tile_rows, static_cast<long long>(sh.num_rows));
@@ -701,6 +705,7 @@ void batch_place_kernel(Src src, BuildShape sh, int num_batches,
             a_drow[at + need] = static_cast<unsigned char>(delta);
         }
     }
+    }
 }
 
 // The same placing pass with the batch's slots assembled in LDS first, in destination order, so that the global
@@ -718,7 +723,7 @@ void batch_place_staged_kernel(Src src, BuildShape sh, int num_batches, int capa
                                const uint2* __restrict__ groups,              // [batches * strips] GroupPlace
                                const unsigned int* __restrict__ meta, const int2* __restrict__ cells_t,
                                float* __restrict__ a_val, unsigned short* __restrict__ a_lcol,
-                               unsigned char* __restrict__ a_drow, unsigned char* __restrict__ todo) {
+                               unsigned char* __restrict__ a_drow, int* __restrict__ todo /*[0] count, [1 ...] batches left over*/) {
     extern __shared__ int stage_lds[];
     __shared__ int s_partial[kBuildBlock / 64];
     const int batch = xcd_contiguous(blockIdx.x, num_batches);
@@ -740,7 +745,7 @@ void batch_place_staged_kernel(Src src, BuildShape sh, int num_batches, int capa
                                                                                 : static_cast<int>(tile_end);
     const long long entry0 = src.offset(row0), entry1 = src.offset(row1);
     if (entry1 - entry0 > capacity) {          // (a batch with long rows inside: the scattered kernel takes it)
-        if (threadIdx.x == 0) todo[batch] = 1;
+        if (threadIdx.x == 0) todo[1 + atomicAdd(&todo[0], 1)] = batch;
         return;
     }
     const int span = static_cast<int>(entry1 - entry0);
@@ -802,7 +807,7 @@ void batch_place_staged_kernel(Src src, BuildShape sh, int num_batches, int capa
     }
     __syncthreads();
     if (total > stage_slots) {                 // (markers galore: more slots than the staging area holds)
-        if (threadIdx.x == 0) todo[batch] = 1;
+        if (threadIdx.x == 0) todo[1 + atomicAdd(&todo[0], 1)] = batch;
         return;
     }
 
@@ -1939,7 +1944,7 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     long long* block_sum = nullptr;    // scan scratch; [blocks] sums, then [blocks] grand total, [blocks + 1] entry count
     uint2* groups = nullptr;
     unsigned int* meta = nullptr;      // per-entry records between the ranking and the placing pass
-    unsigned char* place_todo = nullptr;   // batches the staged placing pass left to the scattered one
+    int* place_todo = nullptr;             // [0] how many, [1 ...] which batches the staged placing pass left to the scattered one
     BuildArena first, second;     // what is known up front; what depends on the batch count
     auto cleanup = [&](hipError_t e) {
         for (void* q : {static_cast<void*>(first.base), static_cast<void*>(second.base), static_cast<void*>(strip_begin)}) {
@@ -2005,14 +2010,14 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
                   BuildArena::padded(static_cast<size_t>(std::max(num_batches, 1)) * sizeof(int)) +
                   BuildArena::padded(static_cast<size_t>(std::max<long long>(group_count, 1)) * sizeof(uint2)) +
                   BuildArena::padded(static_cast<size_t>(std::max<long long>(plan->csr_nnz, 1)) * sizeof(unsigned int)) +
-                  BuildArena::padded(static_cast<size_t>(std::max(num_batches, 1)));
+                  BuildArena::padded((static_cast<size_t>(std::max(num_batches, 1)) + 1) * sizeof(int));
     e = hipMalloc(reinterpret_cast<void**>(&second.base), second.size);
     if (e == hipSuccess) {
         batch_row = second.take<int>(static_cast<long long>(num_batches) + 1);
         batch_tile = second.take<int>(num_batches);
         groups = second.take<uint2>(group_count);
         meta = second.take<unsigned int>(plan->csr_nnz);
-        place_todo = second.take<unsigned char>(num_batches);
+        place_todo = second.take<int>(static_cast<long long>(num_batches) + 1);
     }
     if (e == hipSuccess && has_long_path) {
         e = dev_alloc(&plan->long_rows, plan->csr_nnz / std::max(plan->long_row, 1) + 1);
@@ -2062,12 +2067,12 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
         // staged placing pass (contiguous segments); the batches it cannot hold are flagged for the scattered one
         bool staged = true;
         if (const char* env = std::getenv("SPMV_TILED_PLACE")) staged = std::strcmp(env, "scattered") != 0;
-        unsigned char* todo = place_todo;
+        int* todo = place_todo;
         if (staged) {
             const int stage_slots = (capacity + 1024 + 63) / 64 * 64;
             const size_t stage_lds = static_cast<size_t>(kStageBytesPerStrip) * S + static_cast<size_t>(kStageBytesPerSlot) * stage_slots;
             staged = stage_lds + sizeof(int) * kBuildBlock + 64 <= 160 * 1024;
-            if (staged) e = hipMemsetAsync(todo, 0, num_batches, s);
+            if (staged) e = hipMemsetAsync(todo, 0, sizeof(int), s);
             if (staged && e == hipSuccess) {
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&batch_place_staged_kernel<Src>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(stage_lds));
@@ -2079,7 +2084,7 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
                     plan->a_val, plan->a_lcol, plan->a_drow, todo);
             }
         }
-        batch_place_kernel<Src><<<xcd_grid(num_batches), kBuildBlock, 12 * static_cast<size_t>(S), s>>>(
+        batch_place_kernel<Src><<<staged ? std::min(xcd_grid(num_batches), 512) : xcd_grid(num_batches), kBuildBlock, 12 * static_cast<size_t>(S), s>>>(
             dev_src, sh, num_batches, batch_row, batch_tile, groups, meta, reinterpret_cast<const int2*>(plan->cells_t), plan->a_val, plan->a_lcol, plan->a_drow,
             staged ? todo : nullptr);
         cell_padding_kernel<<<static_cast<int>(std::min<long long>((cells + kBlock - 1) / kBlock, 4096)), kBlock, 0, s>>>(

@@ -70,17 +70,59 @@ def csr_bytes(rows, cols, nnz):
 # already initialised the GPU, so this process must not start another program) or with
 # SPMV_BENCH_INPROCESS=1 the run stays in this process and prints its line from a `finally`.
 def _under_profiler():
-    preload = os.environ.get("LD_PRELOAD", "")
-    return "rocprof" in preload or any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ)
+    """True when a tool library has (or may have) initialised the GPU in THIS process before main() runs: then this
+    process must not start another program (the pool forbids that hop) and the run stays in-process.  Recognised: a
+    preloaded profiler / HIP / HSA library, the rocprofiler tool-library variables, any ROCPROF* / ROCP_ variable.
+    A wrapper this does not recognise sets SPMV_BENCH_INPROCESS=1 (tools/README.md)."""
+    preload = os.environ.get("LD_PRELOAD", "").lower()
+    if any(tag in preload for tag in ("rocprof", "libhsa", "libamdhip", "roctracer", "roctx", "omnitrace", "rocsys", "rocprofiler")):
+        return True
+    if os.environ.get("HSA_TOOLS_LIB") or os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("ROCP_TOOL_LIB"):
+        return True
+    return any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ)
 
 
-def supervise(child_cmd=None):
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launcher_command(gpus, argv):
+    """`python bench.py --gpus N` started plainly (no rank variables): the supervisor — a process that never touches
+    the GPU — starts torch.distributed.run itself, one measuring child per GPU (the driver's own launch line)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def _ending(returncode):
+    import signal
+    if returncode is None:
+        return "still running (killed by the supervisor)"
+    if returncode < 0:
+        try:
+            return "signal " + signal.Signals(-returncode).name
+        except ValueError:
+            return "signal %d" % -returncode
+    return "exit code %d" % returncode
+
+
+def supervise(child_cmd=None, self_launched=False):
+    """Deadlines (all wall clock of THIS process, so a SIGKILL at the caller's limit is never what ends the run):
+    SPMV_BENCH_BUDGET (default 540 s: the driver runs bench.py under 600 s) bounds the whole run; a child that has not
+    measured by SPMV_BENCH_MEASURE_DEADLINE (default budget - 120 s) is killed and the exit code is non-zero; the extras
+    end SPMV_BENCH_EXTRAS_DEADLINE seconds after the measurement (default 300) or 20 s before the budget, whichever
+    comes first."""
     import signal
     import subprocess
     import threading
 
+    started = time.time()
     rank = int(os.environ.get("RANK", "0"))
     env = dict(os.environ, SPMV_BENCH_CHILD="1")
+    if self_launched:
+        env["SPMV_BENCH_SELF_LAUNCHED"] = "1"          # ranks other than 0 then write nothing to the shared stdout
     child = subprocess.Popen(child_cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                              stdout=subprocess.PIPE, env=env)       # same process group: whoever ends the job ends the child too
     state = {"line": None, "measured_at": None, "final": False}
@@ -95,6 +137,9 @@ def supervise(child_cmd=None):
                 obj = json.loads(text)
             except ValueError:
                 print(text, file=sys.stderr, flush=True)  # a library wrote to the child's stdout: not ours
+                continue
+            if not isinstance(obj, dict) or "metric" not in obj:
+                print(text, file=sys.stderr, flush=True)
                 continue
             state["line"] = obj
             state["final"] = not obj.get("provisional", False)
@@ -111,29 +156,45 @@ def supervise(child_cmd=None):
                 child.wait(timeout=10)
             except Exception:                           # noqa: BLE001
                 pass
+            killed = True
+        else:
+            killed = False
         thread.join(timeout=5)
         obj = state["line"]
+        ending = _ending(child.returncode) + (" after the supervisor killed it" if killed else "")
         if obj is not None and rank == 0:
             if obj.pop("provisional", False):          # (a final line is complete whatever ends the child afterwards)
-                obj["incomplete"] = reason or "the run ended before its last extra (exit code %s)" % child.returncode
+                obj["incomplete"] = reason or "the run ended before its last extra (%s)" % ending
+            # how the measuring child ended, always: a fault behind the final line (teardown, an opt-in trial) stays findable
+            obj["child_exit"] = ending
             sys.stdout.write(json.dumps(obj) + "\n")
             sys.stdout.flush()
+        if child.returncode not in (0, None) or killed:
+            print("[bench] measuring child: %s%s" % (ending, "; " + reason if reason else ""), file=sys.stderr, flush=True)
         measured = state["measured_at"] is not None
         rc = child.returncode if child.returncode is not None else -9
         os._exit(0 if measured else (rc if rc > 0 else 1))
 
     for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
         signal.signal(sig, lambda number, frame: finish("signal %d while the extras were running" % number))
-    deadline = float(os.environ.get("SPMV_BENCH_EXTRAS_DEADLINE", "1500"))
+    budget = float(os.environ.get("SPMV_BENCH_BUDGET", "540"))
+    measure_deadline = float(os.environ.get("SPMV_BENCH_MEASURE_DEADLINE", str(max(budget - 120.0, 30.0))))
+    extras_deadline = float(os.environ.get("SPMV_BENCH_EXTRAS_DEADLINE", "300"))
     final_at = None
     while child.poll() is None:
         time.sleep(0.2)
         now = time.time()
         if state["final"] and final_at is None:
             final_at = now
-        if state["measured_at"] is not None and not state["final"] and now - state["measured_at"] > deadline:
-            finish("the extras did not finish within %.0f s of the measurement: child killed" % deadline)
-        if final_at is not None and now - final_at > deadline:       # opt-in trials or the teardown hang behind a complete line
+        if state["measured_at"] is None:
+            if now - started > measure_deadline:
+                finish("no measurement within %.0f s: child killed" % measure_deadline)
+            continue
+        out_of_budget = now - started > budget - 20.0
+        if not state["final"] and (now - state["measured_at"] > extras_deadline or out_of_budget):
+            finish("the extras did not finish within %s: child killed"
+                   % ("the run's budget of %.0f s" % budget if out_of_budget else "%.0f s of the measurement" % extras_deadline))
+        if final_at is not None and (now - final_at > extras_deadline or out_of_budget):   # trials or the teardown hang behind a complete line
             finish(None)
     finish(None)
 
@@ -156,9 +217,14 @@ def _fail_here(stage):
 
 def main():
     args = parse()
-    if os.environ.get("SPMV_BENCH_CHILD") != "1" and os.environ.get("SPMV_BENCH_INPROCESS", "0") != "1" \
-            and not _under_profiler():
-        supervise()                                   # never returns
+    if os.environ.get("SPMV_BENCH_CHILD") != "1":
+        if os.environ.get("SPMV_BENCH_INPROCESS", "0") == "1" or _under_profiler():
+            print("[bench] running in this process (profiler or SPMV_BENCH_INPROCESS=1): no supervisor", file=sys.stderr, flush=True)
+        elif args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            print("[bench] --gpus %d without a launcher: starting torch.distributed.run" % args.gpus, file=sys.stderr, flush=True)
+            supervise(launcher_command(args.gpus, sys.argv[1:]), self_launched=True)      # never returns
+        else:
+            supervise()                               # never returns
     # The contract: stdout carries exactly ONE line, the JSON.  Libraries write there too (RCCL prints a version
     # banner on stdout when a communicator is created), so file descriptor 1 is pointed at stderr for the run and
     # the line goes out through a private duplicate of the real stdout.
@@ -279,7 +345,7 @@ def main():
         return seconds
 
     elapsed = timed(pr, engine)
-    if rank != 0 and os.environ.get("SPMV_BENCH_CHILD") == "1":
+    if rank != 0 and os.environ.get("SPMV_BENCH_CHILD") == "1" and os.environ.get("SPMV_BENCH_SELF_LAUNCHED") != "1":
         os.write(result_fd, b"MEASURED\n")          # tells this rank's supervisor that the timed region is over
 
     bytes_per_step = csr_bytes(n, n, nnz_total)
@@ -386,6 +452,7 @@ def main():
         try:
             _fail_here(name)
             fn()
+            result.setdefault("extras_done", []).append(name)
         except Exception as exc:                                    # noqa: BLE001
             result.setdefault("extras_failed", {})[name] = repr(exc)
         emit(False)
@@ -414,6 +481,14 @@ def main():
                                           "rank_sum": rank_sum,
                                           "note": "seconds_total = a call with plan and workspace warm, result delivered in the "
                                                   "library's pinned array; seconds_first_call also allocates them"}
+
+            def do_cpu_pagerank():
+                # the reference's HOST loop (src/pagerank.cu:50-153, restated in oracle_pagerank) on the same
+                # matrix, stopped after as many iterations as the GPU call above took
+                gpu_iterations = (result.get("pagerank_api") or {}).get("iterations") or 3
+                if result.get("cpu_baseline"):
+                    result["cpu_baseline"]["pagerank"] = cpu_pagerank_baseline(row_ptrs, cols_v, vals_v, n, gpu_iterations,
+                                                                               result.get("pagerank_api"))
 
             def do_api_table():
                 result["spmv_csr_api"] = api_table(spmv, wl, engine, n, k, args.seed)
@@ -457,6 +532,7 @@ def main():
             result["cpu_baseline"] = None
             extra("cpu_baseline", do_cpu_baseline)     # the contract's other object: first, and it touches no kernel
             extra("pagerank_api", do_pagerank_api)
+            extra("cpu_baseline_pagerank", do_cpu_pagerank)
             extra("spmv_csr_api", do_api_table)
             extra("parity_report", do_parity_report)
             extra("values_folded", do_folded)
@@ -589,7 +665,14 @@ def api_table(spmv, wl, engine, n, k, seed):
         y = spmv.CudaBuffer(rows)
         b = csr_bytes(rows, cols, nnz)
         for kt, label in kernels:
-            t = wl.time_spmv_csr(handle, x, y, kt % 10, use_texture=kt >= 10)
+            # "..._direct": the kernel the caller spelled, promotion to the tiled engine switched off for the row
+            promotion = spmv.get_tiled_promotion()
+            if label.endswith("_direct"):
+                spmv.set_tiled_promotion(0)
+            try:
+                t = wl.time_spmv_csr(handle, x, y, kt % 10, use_texture=kt >= 10)
+            finally:
+                spmv.set_tiled_promotion(promotion)
             avg = float(np.mean(t))
             table[f"{name}/{label}"] = {"avg_us": round(avg * 1e3, 1), "min_us": round(float(np.min(t)) * 1e3, 1),
                                         "GBps": round(b / avg / 1e6, 1), "frac": round(b / avg / 1e6 / HBM_PEAK_GBS, 4),
@@ -597,14 +680,19 @@ def api_table(spmv, wl, engine, n, k, seed):
         x.release()
         y.release()
 
-    # "+lds_tiles" = SpMVConfig::use_texture (what spmv_auto_config sets for cols > 10000)
-    run("c5_10Mx16", engine._A, n, n, n * k, [(11, "vector+lds_tiles"), (1, "vector"), (2, "merge")])
+    # "+lds_tiles" = SpMVConfig::use_texture (what spmv_auto_config sets for cols > 10000); "vector" / "merge" = what the
+    # reference's own callers pass ({VECTOR_CSR, 256, false}, benchmarks/main.cu:52-56): the direct kernel for the first
+    # calls, the tiled engine once the matrix has been promoted (the protocol's 5 warm-up calls are past that point);
+    # "..._direct" = the same call with promotion off
+    table["note"] = ("vector / merge rows: SpMVConfig without use_texture, measured after the library's promotion to the LDS-tiled "
+                     "engine (spmv_set_tiled_promotion, default after 4 calls); *_direct rows: promotion off")
+    run("c5_10Mx16", engine._A, n, n, n * k, [(11, "vector+lds_tiles"), (1, "vector"), (2, "merge"), (1, "vector_direct"), (2, "merge_direct")])
     A = wl.uniform_csr_device(seed, 1_000_000, 1_000_000, 16)
-    run("c2_1Mx16", A.handle, A.rows, A.cols, A.nnz, [(11, "vector+lds_tiles"), (1, "vector"), (2, "merge"), (0, "scalar")])
+    run("c2_1Mx16", A.handle, A.rows, A.cols, A.nnz, [(1, "vector_direct"), (2, "merge_direct"), (0, "scalar"), (1, "vector"), (2, "merge"), (11, "vector+lds_tiles")])
     A.close()
     P = wl.power_law_csr_device(seed, 1_000_000, 1_000_000)
     run("c4_1M_powerlaw_nnz%d" % P.nnz, P.handle, P.rows, P.cols, P.nnz,
-        [(12, "merge+lds_tiles"), (2, "merge"), (1, "vector")])
+        [(2, "merge_direct"), (1, "vector_direct"), (2, "merge"), (12, "merge+lds_tiles")])
     P.close()
     # config 3: ELL 1M x 32 (column-major), built from a uniform CSR on the host side of the C ABI
     E = wl.uniform_ell_device(seed, 1_000_000, 1_000_000, 32)
@@ -629,6 +717,8 @@ def parity_report(spmv, wl, seed):
     whose terms cancel; any kernel that reorders a row's sum has them on signed data).  Checker: oracle/."""
     oracle = importlib.import_module("oracle")
     out = {}
+    promotion = spmv.get_tiled_promotion()
+    spmv.set_tiled_promotion(0)            # every row is the kernel it names (a cached plan would otherwise take the vector / merge rows)
 
     def check(name, A, kernels):
         rp, ci, va = A.to_host()
@@ -661,6 +751,7 @@ def parity_report(spmv, wl, seed):
     P = wl.power_law_csr_device(seed, 1_000_000, 1_000_000)
     check("c4_1M_powerlaw", P, [(12, "merge+lds_tiles"), (2, "merge"), (1, "vector")])
     P.close()
+    spmv.set_tiled_promotion(promotion)
     return out
 
 
@@ -720,6 +811,30 @@ def cpu_baseline(spmv, row_ptrs, cols, vals, n, nnz):
                 "sample": "same matrix, OpenMP static row blocks, best of %d after 1 warm-up; threads = %s" % (reps, share_source),
                 "checksum": float(np.float64(y1.sum(dtype=np.float64)))}
     return single, parallel
+
+
+def cpu_pagerank_baseline(row_ptrs, cols, vals, n, iterations, gpu_call):
+    """The reference's PageRank HOST loop (src/pagerank.cu:50-153: dangling scan, then per iteration the dangling sum, one
+    spmv_cpu_csr, the update and the fp32 residual) as restated in oracle/spmv_oracle.c, one host thread, on the same
+    column-stochastic matrix, tolerance 0 and max_iterations = the GPU call's iteration count."""
+    oracle = importlib.import_module("oracle")
+    rp, ci, va = row_ptrs.cpu().numpy(), cols.cpu().numpy(), vals.cpu().numpy()
+    t0 = time.perf_counter()
+    ranks, done, residual, _ = oracle.pagerank(rp, ci, va, num_cols=n, damping=0.85, tolerance=0.0, max_iterations=int(iterations))
+    seconds = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.dangling_mask(rp, ci, va, n)                   # the loop's one-time part (src/pagerank.cu:20-48), timed alone
+    setup = time.perf_counter() - t0
+    per_iter = max(seconds - setup, 1e-9) / max(done, 1)
+    out = {"value": round(1.0 / per_iter, 3), "unit": "iterations/s", "cores": 1, "kind": "port",
+           "iterations": int(done), "seconds_total": round(seconds, 3), "seconds_dangling_scan": round(setup, 3),
+           "final_residual": residual, "rank_sum": float(ranks.sum(dtype=np.float64)),
+           "sample": "oracle_pagerank (the host loop of src/pagerank.cu:50-153 restated in C; src/pagerank.cu itself needs the CUDA "
+                     "runtime to link) on the full workload matrix, %d iterations (what the GPU pagerank() call took), tolerance 0; "
+                     "value = iterations / (total - dangling scan)" % done}
+    if gpu_call and gpu_call.get("iterations"):
+        out["gpu_iterations_per_s_incl_setup"] = round(gpu_call["iterations"] / max(gpu_call["seconds_total"], 1e-9), 1)
+    return out
 
 
 if __name__ == "__main__":

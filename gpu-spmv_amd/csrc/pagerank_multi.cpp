@@ -133,10 +133,13 @@ struct DeviceShard {
     CSRMatrix header;               // wraps the three arrays (side-table key for the tiled plan)
     detail::PrShard shard;
     ncclComm_t comm = nullptr;
-    // The communicator is used by this shard's host thread (collectives) and, on a failure elsewhere, by the failing
-    // thread (ncclCommAbort): both under comm_lock, and an aborted communicator is never touched again.
+    // The communicator is used by this shard's host thread (collectives, under comm_lock) and, on a failure elsewhere,
+    // by the failing thread (ncclCommAbort).  The abort never WAITS for comm_lock: a peer blocked on the host inside
+    // its collective (connection setup of the first one, a proxy wait) holds that lock until the very abort releases
+    // it.  `comm_aborted` is exchanged atomically, so each communicator is aborted exactly once, and the
+    // owner looks at it (under its lock) before it starts a collective: an aborted communicator is never used again.
     std::unique_ptr<std::mutex> comm_lock{new std::mutex};
-    bool comm_aborted = false;      // ncclCommAbort already released it
+    std::unique_ptr<std::atomic<bool>> comm_aborted{new std::atomic<bool>(false)};      // ncclCommAbort already released it
     bool have_header = false;
     hipStream_t side_stream = nullptr;      // overlapped exchange: the collectives / copies run here
     std::vector<hipEvent_t> block_done;     // ... and block c of the new vector is complete
@@ -148,7 +151,7 @@ void release(std::vector<DeviceShard>& shards, const Rccl* api) {
     for (DeviceShard& d : shards) {
         if (hipSetDevice(d.device) != hipSuccess) continue;
         if (d.stream) (void)hipStreamSynchronize(d.stream);
-        if (d.comm && api && !d.comm_aborted) (void)api->CommDestroy(d.comm);
+        if (d.comm && api && !d.comm_aborted->load()) (void)api->CommDestroy(d.comm);
         if (d.have_header) detail::aux_drop(d.header.d_row_ptrs);          // the shard's tiled plan, if any
         for (void* p : {static_cast<void*>(d.d_row_ptrs), static_cast<void*>(d.d_cols), static_cast<void*>(d.d_vals),
                         static_cast<void*>(d.d_mask), static_cast<void*>(d.r[0]), static_cast<void*>(d.r[1]),
@@ -398,7 +401,7 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
                         }
                     } else {
                         std::lock_guard<std::mutex> mine_only(*d.comm_lock);
-                        fine = !aborted.load() && !d.comm_aborted
+                        fine = !aborted.load() && !d.comm_aborted->load()
                             && api->AllGather(mine + p * piece, mine, static_cast<size_t>(piece), ncclFloat, d.comm, xs) == ncclSuccess;
                     }
                     if (fine && side) {
@@ -430,11 +433,12 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
             aborted.store(true);
             if (api && api->CommAbort) {
                 for (DeviceShard& other : shards) {
-                    std::lock_guard<std::mutex> one_at_a_time(*other.comm_lock);     // each communicator exactly once
-                    if (other.comm && !other.comm_aborted) {
-                        (void)api->CommAbort(other.comm);
-                        other.comm_aborted = true;
-                    }
+                    if (!other.comm) continue;
+                    // Owner not inside a collective: abort under its lock, so that it cannot start one meanwhile.  Owner
+                    // inside one (the lock is taken): that call may be exactly what the abort has to release — ncclCommAbort
+                    // is the one call meant to be issued against a communicator in use —, so do not wait for the lock.
+                    std::unique_lock<std::mutex> idle(*other.comm_lock, std::try_to_lock);
+                    if (!other.comm_aborted->exchange(true)) (void)api->CommAbort(other.comm);     // each communicator exactly once
                 }
             }
         }

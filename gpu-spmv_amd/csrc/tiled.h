@@ -41,6 +41,14 @@ struct TiledPlan {
     int* items = nullptr;           // [3 * num_items]
     int  num_items = 0;
     int* strip_first_item = nullptr; // HOST [num_strips + 1]: the items are sorted by strip
+    // EXPERIMENT (SPMV_TILED_PARTS=n): the tiles cut into n row parts; behind the strip-major items a second,
+    // part-major list (per part: every strip's slots of that part's tiles), so that phase 2 of part p can run
+    // beside phase 1 of part p + 1 on a side stream
+    int num_parts = 1;
+    std::vector<int> part_first_tile;   // HOST [parts + 1]
+    std::vector<int> part_first_item;   // HOST [parts + 1] (absolute indices into items)
+    mutable hipStream_t side_stream = nullptr;
+    mutable std::vector<hipEvent_t> part_events;   // [parts]: [p] = phase 1 of part p enqueued; [parts - 1] = join
 
     // rows longer than long_row: summed by one wavefront per 512-entry chunk from the CSR arrays
     int*   long_rows = nullptr;     // [num_long] ascending

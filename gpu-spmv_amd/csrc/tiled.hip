@@ -86,6 +86,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
+// EXPERIMENT: non-temporal hints on the once-read / once-written streams (SPMV_NT_MASK: 1 = phase-1 loads,
+// 2 = phase-1 product stores, 4 = phase-2 loads)
+#ifndef SPMV_NT_MASK
+#define SPMV_NT_MASK 0
+#endif
+template <int BIT, typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+    if constexpr ((SPMV_NT_MASK & BIT) != 0) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <int BIT, typename T>
+__device__ __forceinline__ void stream_store(T* p, T v) {
+    if constexpr ((SPMV_NT_MASK & BIT) != 0) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each XCD has its
 // own L2).  Both phases hand every XCD a CONTIGUOUS range of the work list, walked in order:
 // neighbours in the list then run on one XCD at about the same time and share what they both
@@ -1182,7 +1198,7 @@ void tiled_expand_kernel(const int* __restrict__ items, int first_item, int num_
     // four entries per lane per step, groups aligned to 4 entries (16-byte loads and stores)
     for (int q = (begin & ~3) + threadIdx.x * 4; q < end; q += kExpandBlock * 4) {
         if (q >= begin && q + 3 < end) {
-            const u16x4 c = *reinterpret_cast<const u16x4*>(a_lcol + q);
+            const u16x4 c = stream_load<1>(reinterpret_cast<const u16x4*>(a_lcol + q));
             f32x4 p;
             if (FOLD) {
                 p[0] = xs[c[0]];
@@ -1190,13 +1206,13 @@ void tiled_expand_kernel(const int* __restrict__ items, int first_item, int num_
                 p[2] = xs[c[2]];
                 p[3] = xs[c[3]];
             } else {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(a_val + q);
+                const f32x4 v = stream_load<1>(reinterpret_cast<const f32x4*>(a_val + q));
                 p[0] = v[0] * xs[c[0]];
                 p[1] = v[1] * xs[c[1]];
                 p[2] = v[2] * xs[c[2]];
                 p[3] = v[3] * xs[c[3]];
             }
-            *reinterpret_cast<f32x4*>(prod + q) = p;
+            stream_store<2>(reinterpret_cast<f32x4*>(prod + q), p);
         } else {
             for (int k = max(q, begin); k < min(q + 4, end); ++k) {
                 prod[k] = FOLD ? xs[a_lcol[k]] : a_val[k] * xs[a_lcol[k]];
@@ -1465,6 +1481,9 @@ __device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int 
         unsigned int d;
     };
     int row_carry = 0;                     // wave-uniform: the row the open run has reached (0 at a run's start)
+#if defined(SPMV_PROBE_P2)
+    float probe_acc = 0.f;
+#endif
 
     // The (begin, length) records of the wavefront's runs come 64 at a time (lane l holds run window_first + l); inside
     // a window everything below is scalar arithmetic on v_readlane'd values — no load but the two of a pass, so the
@@ -1512,10 +1531,21 @@ __device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int 
 #pragma unroll
             for (int k = 1; k < kSegs; ++k) base = at >= ps.start[k] && ps.valid ? ps.base[k] : base;
             const unsigned int slot = static_cast<unsigned int>(base + 4 * at);
-            ps.p = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(prod) + (static_cast<size_t>(slot) << 2));
-            ps.d = *reinterpret_cast<const unsigned int*>(a_drow + slot);
+            ps.p = stream_load<4>(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(prod) + (static_cast<size_t>(slot) << 2)));
+            ps.d = stream_load<4>(reinterpret_cast<const unsigned int*>(a_drow + slot));
         };
         auto process = [&](const Pass& ps) {
+#if defined(SPMV_PROBE_P2) && SPMV_PROBE_P2 == 10       // timing probe: loads only (no decode, no LDS adds); results wrong
+            probe_acc += ps.p[0] + ps.p[1] + ps.p[2] + ps.p[3] + __uint_as_float(ps.d);
+            return;
+#elif defined(SPMV_PROBE_P2) && SPMV_PROBE_P2 == 12     // timing probe: loads + LDS adds, rows without any decode; results wrong
+            {
+                const int fake = (lane * 4 + static_cast<int>(ps.d & 0xFF)) % (R - 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(&tile[fake + e], static_cast<double>(ps.p[e]));
+                return;
+            }
+#endif
             const unsigned int word = lane < ps.groups ? ps.d : 0xFFFFFFFFu;
             int delta[4], upto[4], sum = 0;
 #pragma unroll
@@ -1537,11 +1567,16 @@ __device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int 
             }
             const int lane_base = lane_origin + incl - sum;
             row_carry = ps.open_end ? origin + __builtin_amdgcn_readlane(incl, max(ps.groups - 1, 0)) : 0;
+#if defined(SPMV_PROBE_P2) && SPMV_PROBE_P2 == 11       // timing probe: loads + decode, no LDS adds; results wrong
+#pragma unroll
+            for (int e = 0; e < 4; ++e) probe_acc += ps.p[e] * static_cast<float>(delta[e] != kSkip ? lane_base + upto[e] : lane);
+#else
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 double* target = delta[e] != kSkip ? &tile[lane_base + upto[e]] : &spare[lane];
                 atomicAdd(target, static_cast<double>(ps.p[e]));
             }
+#endif
         };
 
         // kDepth passes in flight, pass i of the stream in slot i mod kDepth; every slot always holds issued loads
@@ -1561,20 +1596,24 @@ __device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int 
             }
         }
     }
+#if defined(SPMV_PROBE_P2)
+    tile[threadIdx.x] += static_cast<double>(probe_acc);
+#endif
     __syncthreads();
 }
 
 // The tile (R doubles, R = plan.tile_rows: any multiple of 64) lives in dynamic LDS.
 template <int kReduceBlock, int E, int kRuns>
 __global__ __launch_bounds__(kReduceBlock, kReduceBlock / 128)     // two tiles per CU: 8 (1024 threads) or 4 wavefronts per SIMD
-void tiled_reduce_kernel(int R, int num_tiles, const int2* __restrict__ cells_t, int num_strips,
+void tiled_reduce_kernel(int R, int first_tile, int num_tiles, const int2* __restrict__ cells_t, int num_strips,
                          const float* __restrict__ prod,
                          const unsigned char* __restrict__ a_drow,
                          const LongSeeds seeds,
                          int num_rows, float* __restrict__ y) {
     extern __shared__ double tile[];
-    const int tile_index = xcd_contiguous(blockIdx.x, num_tiles);
-    if (tile_index < 0) return;
+    const int window = xcd_contiguous(blockIdx.x, num_tiles);
+    if (window < 0) return;
+    const int tile_index = first_tile + window;
     if constexpr (kRuns == 0) tile_accumulate_stream<kReduceBlock, SPMV_STREAM_SEGS>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_drow, seeds);
     else tile_accumulate<kReduceBlock, E, kRuns>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_drow, seeds);
     const long long first = static_cast<long long>(tile_index) * R;
@@ -1755,13 +1794,13 @@ LongSeeds long_seeds(const TiledPlan& plan, const Scratch& sc) {
 }
 
 template <int BLOCK, int E, int kRuns>
-hipError_t launch_reduce_as(const TiledPlan& plan, const Scratch& sc, float* d_y, hipStream_t s) {
+hipError_t launch_reduce_as(const TiledPlan& plan, const Scratch& sc, int first_tile, int num_tiles, float* d_y, hipStream_t s) {
     const size_t lds = static_cast<size_t>(plan.tile_rows) * sizeof(double);
     const void* kernel = reinterpret_cast<const void*>(&tiled_reduce_kernel<BLOCK, E, kRuns>);
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
-    tiled_reduce_kernel<BLOCK, E, kRuns><<<xcd_grid(plan.num_tiles), BLOCK, lds, s>>>(
-        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, sc.prod, plan.a_drow,
+    tiled_reduce_kernel<BLOCK, E, kRuns><<<xcd_grid(num_tiles), BLOCK, lds, s>>>(
+        plan.tile_rows, first_tile, num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, sc.prod, plan.a_drow,
         long_seeds(plan, sc), plan.num_rows, d_y);
     return hipGetLastError();
 }
@@ -1775,12 +1814,12 @@ bool stream_form() {
     return on;
 }
 
-hipError_t launch_reduce(const TiledPlan& plan, const Scratch& sc, float* d_y, hipStream_t s) {
-    if (stream_form()) return launch_reduce_as<1024, 4, 0>(plan, sc, d_y, s);
+hipError_t launch_reduce(const TiledPlan& plan, const Scratch& sc, int first_tile, int num_tiles, float* d_y, hipStream_t s) {
+    if (stream_form()) return launch_reduce_as<1024, 4, 0>(plan, sc, first_tile, num_tiles, d_y, s);
     switch (plan.lane_entries) {
-        case 2:  return launch_reduce_as<1024, 2, 4>(plan, sc, d_y, s);
-        case 4:  return launch_reduce_as<1024, 4, 2>(plan, sc, d_y, s);
-        default: return launch_reduce_as<1024, 8, 1>(plan, sc, d_y, s);
+        case 2:  return launch_reduce_as<1024, 2, 4>(plan, sc, first_tile, num_tiles, d_y, s);
+        case 4:  return launch_reduce_as<1024, 4, 2>(plan, sc, first_tile, num_tiles, d_y, s);
+        default: return launch_reduce_as<1024, 8, 1>(plan, sc, first_tile, num_tiles, d_y, s);
     }
 }
 
@@ -1897,6 +1936,8 @@ void tiled_free(TiledPlan* p) {
         if (e.prod) (void)hipFree(e.prod);
         if (e.long_sums) (void)hipFree(e.long_sums);
     }
+    for (hipEvent_t ev : p->part_events) if (ev) (void)hipEventDestroy(ev);
+    if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
     delete[] p->strip_first_item;
     delete p;
 }
@@ -2308,6 +2349,45 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     }
     plan->num_items = static_cast<int>(items.size() / 3);
     plan->strip_first_item[plan->num_strips] = plan->num_items;
+    if (const char* env = std::getenv("SPMV_TILED_PARTS")) {
+        plan->num_parts = std::max(1, std::min({std::atoi(env), 8, plan->num_tiles}));
+    }
+    if (plan->num_parts > 1) {
+        const int n = plan->num_parts, S = plan->num_strips;
+        std::vector<std::vector<int>> bound(n + 1, std::vector<int>(S));
+        std::vector<int> row(2 * static_cast<size_t>(S));
+        plan->part_first_tile.assign(n + 1, 0);
+        for (int p = 0; p <= n; ++p) plan->part_first_tile[p] = static_cast<int>(static_cast<long long>(plan->num_tiles) * p / n);
+        for (int strip = 0; strip < S; ++strip) {
+            bound[0][strip] = host_strip[strip];
+            bound[n][strip] = host_strip[strip + 1];
+        }
+        for (int p = 1; p < n; ++p) {
+            e = hipMemcpy(row.data(), plan->cells_t + 2LL * plan->part_first_tile[p] * S, row.size() * sizeof(int), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return fail(e);
+            for (int strip = 0; strip < S; ++strip) bound[p][strip] = row[2 * strip];
+        }
+        plan->part_first_item.assign(n + 1, 0);
+        for (int p = 0; p < n; ++p) {
+            plan->part_first_item[p] = static_cast<int>(items.size() / 3);
+            for (int strip = 0; strip < S; ++strip) {
+                const int begin = bound[p][strip], stop = bound[p + 1][strip];
+                const int pieces = (stop - begin + item_entries - 1) / item_entries;
+                int b = begin;
+                for (int piece = 1; piece <= pieces; ++piece) {
+                    int next = piece == pieces ? stop
+                                               : static_cast<int>(begin + static_cast<long long>(stop - begin) * piece / pieces) / 8 * 8;
+                    next = std::max(next, b);
+                    if (next == b && piece != pieces) continue;
+                    items.push_back(strip);
+                    items.push_back(b);
+                    items.push_back(next);
+                    b = next;
+                }
+            }
+        }
+        plan->part_first_item[n] = static_cast<int>(items.size() / 3);
+    }
     e = dev_alloc(&plan->items, static_cast<long long>(items.size()));
     if (e == hipSuccess && !items.empty()) {
         e = hipMemcpy(plan->items, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice);
@@ -2381,9 +2461,33 @@ hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipSt
     if (e != hipSuccess) return e;
     // two host threads may call on the same stream: the pair of launches must not interleave with another pair
     std::lock_guard<std::mutex> pair(plan.launch_lock);
+    if (plan.num_parts > 1) {
+        // EXPERIMENT: phase 2 of part p on a side stream beside phase 1 of part p + 1
+        const int n = plan.num_parts;
+        if (!plan.side_stream) {
+            if ((e = hipStreamCreateWithFlags(&plan.side_stream, hipStreamNonBlocking)) != hipSuccess) return e;
+            plan.part_events.assign(n, nullptr);
+            for (int p = 0; p < n; ++p) {
+                if ((e = hipEventCreateWithFlags(&plan.part_events[p], hipEventDisableTiming)) != hipSuccess) return e;
+            }
+        }
+        const std::vector<int>& fi = plan.part_first_item;
+        const std::vector<int>& ft = plan.part_first_tile;
+        e = launch_expand(plan, sc, fi[0], fi[1] - fi[0], true, d_x, nullptr, s);
+        for (int p = 1; p < n && e == hipSuccess; ++p) {
+            e = hipEventRecord(plan.part_events[p - 1], s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(plan.side_stream, plan.part_events[p - 1], 0);
+            if (e == hipSuccess) e = launch_reduce(plan, sc, ft[p - 1], ft[p] - ft[p - 1], d_y, plan.side_stream);
+            if (e == hipSuccess) e = launch_expand(plan, sc, fi[p], fi[p + 1] - fi[p], false, d_x, nullptr, s);
+        }
+        if (e == hipSuccess) e = launch_reduce(plan, sc, ft[n - 1], ft[n] - ft[n - 1], d_y, s);
+        if (e == hipSuccess) e = hipEventRecord(plan.part_events[n - 1], plan.side_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, plan.part_events[n - 1], 0);
+        return e;
+    }
     e = launch_expand(plan, sc, 0, plan.num_items, true, d_x, nullptr, s);       // phase 1 + the long rows
     if (e != hipSuccess) return e;
-    return launch_reduce(plan, sc, d_y, s);
+    return launch_reduce(plan, sc, 0, plan.num_tiles, d_y, s);
 }
 
 // After convergence the kernels of both parts return at once: r_new and the product stream stay as the last

@@ -56,60 +56,115 @@ class PeerFailure(RuntimeError):
     """Another rank of the job reported a failure (or the rendezvous store went away): this rank stops too."""
 
 
+class _WatchPoller:
+    """ONE daemon thread per process that polls the rendezvous store for every live FailureWatch (a bench run keeps
+    several ShardedPageRank objects alive: each used to add its own polling thread beside the timed loop)."""
+    _lock = None
+    _thread = None
+    _watches = []
+    _wake = None
+
+    @classmethod
+    def add(cls, watch):
+        import threading
+        if cls._lock is None:
+            cls._lock = threading.Lock()
+            cls._wake = threading.Event()
+        with cls._lock:
+            cls._watches.append(watch)
+            if cls._thread is None or not cls._thread.is_alive():
+                cls._thread = threading.Thread(target=cls._loop, name="spmv-failure-watch", daemon=True)
+                cls._thread.start()
+
+    @classmethod
+    def remove(cls, watch):
+        if cls._lock is None:
+            return
+        with cls._lock:
+            if watch in cls._watches:
+                cls._watches.remove(watch)
+
+    @classmethod
+    def _loop(cls):
+        import time
+        while True:
+            with cls._lock:
+                live = list(cls._watches)
+                if not live:
+                    cls._thread = None
+                    return
+            for watch in live:
+                watch._poll_once()
+            time.sleep(min(w.poll for w in live))
+
+
 class FailureWatch:
     """What one failing rank costs the others (failure detection).
 
     A collective has no way out when a peer never joins it: RCCL waits on the device, gloo in the host call.  So
-    every rank keeps a small daemon thread that looks at one key of the job's rendezvous store a few times per
-    second.  A rank whose loop raises writes its story under that key (`report`) and re-raises — the process ends
-    non-zero by the ordinary route.  A rank that sees the key first gives its main thread `grace` seconds to notice (`check()` is called at the top of every iteration and
-    raises PeerFailure, an ordinary exception the caller may handle); a main thread that does not — because it
-    sits inside the collective the failed rank will never join — is taken down with the process
-    (os._exit(EXIT_PEER_FAILED)), which is what releases the GPU side too.  Nobody hangs, every exit is non-zero.
+    every rank polls a few keys of the job's rendezvous store a few times per second (one thread per process,
+    _WatchPoller).  A rank whose loop raises writes its story under ITS OWN key (`report`) and re-raises — the process
+    ends non-zero by the ordinary route, or the caller handles the exception and carries on: a rank never reads its own
+    key, so its own report cannot take it down later.  A rank that sees ANOTHER rank's key gives its main thread `grace`
+    seconds to notice (`check()` is called at the top of every iteration and raises PeerFailure, an ordinary exception
+    the caller may handle); a main thread that does not — because it sits inside the collective the failed rank will
+    never join — is taken down with the process (os._exit(EXIT_PEER_FAILED)), which is what releases the GPU side too.
+    Nobody hangs, every exit is non-zero.
+
+    The keys belong to ONE watch: they carry the watch's generation (the count of watches this process has created for
+    this job — the ranks create their loops in lockstep, so the number agrees across ranks), and a failure reported
+    against one loop (an exchange trial whose exception the caller swallowed) does not fail the loops created after it.
     """
     KEY = "spmv_amd/rank_failed"
+    _generation = 0
 
     def __init__(self, rank, world, store=None, poll=0.25, grace=5.0):
-        import threading
         self.rank, self.world, self.poll, self.grace = rank, world, poll, grace
         self.store = store
         self.peer_failed = None          # the failed rank's story, once seen
         self.acknowledged = False        # the main thread has seen it (it is on its way out by itself)
-        self._stop = threading.Event()
-        self._thread = None
+        self._seen_at = None
+        self._stopped = False
+        FailureWatch._generation += 1
+        self.generation = FailureWatch._generation
         if self.store is None and world > 1 and dist.is_available() and dist.is_initialized():
             try:
                 from torch.distributed.distributed_c10d import _get_default_store
                 self.store = dist.PrefixStore("spmv_amd_watch", _get_default_store())
             except Exception:           # noqa: BLE001 - no store, no watch
                 self.store = None
+        self._peer_keys = ["%s/%d/%d" % (self.KEY, self.generation, r) for r in range(world) if r != rank]
         if self.store is not None and world > 1:
-            self._thread = threading.Thread(target=self._loop, name="spmv-failure-watch", daemon=True)
-            self._thread.start()
+            _WatchPoller.add(self)
 
-    def _loop(self):
+    def _key(self, rank):
+        return "%s/%d/%d" % (self.KEY, self.generation, rank)
+
+    def _poll_once(self):
+        """Called by the poller thread.  Other ranks' keys only: this rank's own report is not news to it."""
         import os
         import sys
         import time
-        while not self._stop.wait(self.poll):
+        if self._stopped:
+            return
+        if self.peer_failed is None:
             try:
-                failed = self.store.check([self.KEY])
-                story = self.store.get(self.KEY).decode(errors="replace") if failed else None
+                for key in self._peer_keys:
+                    if self.store.check([key]):
+                        self.peer_failed = self.store.get(key).decode(errors="replace")
+                        self._seen_at = time.time()
+                        break
             except Exception:           # noqa: BLE001
                 # The store lives in rank 0's process.  Losing it is what an orderly end of rank 0 looks like as well,
                 # so it is not read as a failure: a rank that dies without a word is the launcher's business
                 # (torch.distributed.run and mp.spawn both end the other workers when one exits non-zero).
+                self.stop()
                 return
-            if not failed:
-                continue
-            self.peer_failed = story
-            deadline = time.time() + self.grace
-            while time.time() < deadline:
-                if self.acknowledged or self._stop.is_set():
-                    return
-                time.sleep(0.05)
+        if self.peer_failed is None or self.acknowledged:
+            return
+        if time.time() - self._seen_at >= self.grace:
             print("[spmv] rank %d: another rank failed (%s) and this rank is blocked in the exchange: leaving with exit "
-                  "code %d" % (self.rank, story, EXIT_PEER_FAILED), file=sys.stderr, flush=True)
+                  "code %d" % (self.rank, self.peer_failed, EXIT_PEER_FAILED), file=sys.stderr, flush=True)
             os._exit(EXIT_PEER_FAILED)
 
     def check(self):
@@ -122,13 +177,21 @@ class FailureWatch:
         """This rank is failing with `exc`: tell the others before going down."""
         if self.store is None or isinstance(exc, PeerFailure):
             return
+        self.acknowledged = True         # whatever the peers report from here on, this rank is already on its way out
         try:
-            self.store.set(self.KEY, "rank %d: %r" % (self.rank, exc))
+            self.store.set(self._key(self.rank), "rank %d: %r" % (self.rank, exc))
         except Exception:               # noqa: BLE001 - best effort on the way out
             pass
 
     def stop(self):
-        self._stop.set()
+        """The loop this watch belongs to is over (ShardedPageRank.close): no more polling for it, and its own key goes."""
+        self._stopped = True
+        _WatchPoller.remove(self)
+        if self.store is not None:
+            try:
+                self.store.delete_key(self._key(self.rank))
+            except Exception:           # noqa: BLE001 - a store without delete, or already gone
+                pass
 
 
 class Layout:

@@ -189,6 +189,11 @@ int spmv_c_spmv_ell(const spmv_c_ell* A, const float* d_x, float* d_y,
                     const spmv_c_config* config, int vec_size, spmv_c_result* out);
 int spmv_c_auto_config(const spmv_c_csr* A, spmv_c_config* out);          /* spmv_auto_config */
 int spmv_c_validate_dimensions(int num_cols, int vec_size);               /* 1 = match */
+/* extension (spmv::spmv_set_tiled_promotion, include/spmv/spmv.h): after `calls` spmv_csr() calls that name
+ * VECTOR_CSR / MERGE_PATH without use_texture on one large matrix, later ones run on the LDS-tiled engine
+ * (default 4, 0 = never; the reference's callers never set use_texture: benchmarks/main.cu:52-56) */
+void spmv_c_set_tiled_promotion(int calls);
+int spmv_c_get_tiled_promotion(void);
 /* extension: 1 when the matrix currently holds an LDS-tiled plan (built by the first
  * use_texture call / PageRank on a large matrix), 0 otherwise */
 int spmv_c_csr_has_tiled_plan(const spmv_c_csr* A);

@@ -33,8 +33,11 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def gpu(spmv):
-    """Fails loudly (no silent CPU route) when a gpu-marked test runs without a device."""
+    """Fails loudly (no silent CPU route) when a gpu-marked test runs without a device.
+    The parity tests name the kernel they test: promotion of VECTOR_CSR / MERGE_PATH callers to the tiled engine
+    (spmv_set_tiled_promotion) is off for the session; tests/test_gpu_spmv.py's promotion test turns it on itself."""
     spmv.require_gpu()
+    spmv.set_tiled_promotion(0)
     return spmv
 
 

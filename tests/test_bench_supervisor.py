@@ -93,3 +93,79 @@ def test_a_hang_behind_the_final_line_is_cut_off_and_the_line_is_complete(tmp_pa
     assert out.returncode == 0, out.stderr
     got = json.loads(out.stdout.strip())
     assert got["value"] == 1.0 and "incomplete" not in got
+
+
+def test_a_child_that_never_measures_is_cut_off_by_the_supervisors_own_clock(tmp_path):
+    """No signal from outside: the supervisor's deadline fires by itself (a SIGKILL at the caller's limit must
+    never be what ends the run), the child is killed, no line, non-zero exit."""
+    out = run_supervisor(tmp_path, """
+        import time
+        time.sleep(600)
+    """, env={"SPMV_BENCH_MEASURE_DEADLINE": "1"}, timeout=60)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert "no measurement within" in out.stderr
+
+
+def test_the_runs_budget_bounds_the_extras_without_any_signal(tmp_path):
+    out = run_supervisor(tmp_path, f"""
+        import json, sys, time
+        print(json.dumps(dict({LINE!r}, provisional=True)), flush=True)
+        time.sleep(600)
+    """, env={"SPMV_BENCH_BUDGET": "22"}, timeout=60)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip())
+    assert "budget" in got["incomplete"] and "killed" in got["child_exit"]
+
+
+def test_how_the_child_ended_is_in_the_line_even_behind_a_final_one(tmp_path):
+    out = run_supervisor(tmp_path, f"""
+        import json, os
+        print(json.dumps({LINE!r}), flush=True)
+        os.abort()
+    """)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip())
+    assert got["child_exit"] == "signal SIGABRT" and "incomplete" not in got
+    assert "SIGABRT" in out.stderr
+
+
+def test_gpus_n_without_rank_variables_starts_the_launcher(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_supervise(cmd=None, self_launched=False):
+        seen["cmd"], seen["self_launched"] = cmd, self_launched
+        raise SystemExit(0)
+
+    monkeypatch.setattr(bench, "supervise", fake_supervise)
+    for name in ("SPMV_BENCH_CHILD", "SPMV_BENCH_INPROCESS", "WORLD_SIZE", "RANK", "LD_PRELOAD", "HSA_TOOLS_LIB"):
+        monkeypatch.delenv(name, raising=False)
+    monkeypatch.setattr(bench, "_under_profiler", lambda: False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    cmd = seen["cmd"]
+    assert seen["self_launched"] and cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    # with a launcher's rank variables in place nothing changes: the plain supervisor
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert seen["cmd"] is None and not seen["self_launched"]
+
+
+@pytest.mark.parametrize("name,value", [("HSA_TOOLS_LIB", "/opt/rocm/lib/librocprofiler-sdk-tool.so"),
+                                        ("LD_PRELOAD", "/usr/lib/libomnitrace-dl.so"),
+                                        ("ROCP_TOOL_LIBRARIES", "x.so"), ("ROCPROF_COUNTERS", "1")])
+def test_tool_libraries_that_initialise_the_gpu_keep_the_run_in_process(monkeypatch, name, value):
+    sys.path.insert(0, ROOT)
+    import bench
+    for var in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCP_TOOL_LIB"):
+        monkeypatch.delenv(var, raising=False)
+    for var in [k for k in os.environ if k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_"))]:
+        monkeypatch.delenv(var, raising=False)
+    assert not bench._under_profiler()
+    monkeypatch.setenv(name, value)
+    assert bench._under_profiler()

@@ -60,3 +60,17 @@ def test_two_ranks_a_failing_exchange_trial_still_leaves_the_line(gpu, how):
                          capture_output=True, text=True, timeout=1200, env=env)
     line = one_line(out)
     assert line["n_gpus"] == 2 and line["config"]["exchange"] == "gather" and line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_plain_launch_with_two_gpus_starts_its_own_launcher(gpu):
+    """`python bench.py --gpus 2` the way the driver starts `--gpus 1` (no torch.distributed.run in front, no rank variables):
+    the supervisor starts the launcher itself and exactly one line with n_gpus = 2 comes out."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SPMV_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-extras"] + SMALL,
+                         capture_output=True, text=True, timeout=1200, env=env)
+    line = one_line(out)
+    assert line["n_gpus"] == 2 and line["config"]["exchange"] == "gather" and line["value"] > 0
+    assert line["child_exit"] == "exit code 0" and "incomplete" not in line
+    assert "starting torch.distributed.run" in out.stderr

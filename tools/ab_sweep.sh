@@ -9,7 +9,7 @@ for round in 1 2 3; do
   i=0
   for cfg in "$@"; do
     i=$((i + 1))
-    env $cfg python tools/quick_bench.py $WHICH 2>&1 | grep "kernel=" | sed "s/^/cfg$i round$round [$cfg] /" >> $out
+    env $cfg python tools/quick_bench.py $WHICH 2>&1 | grep "kernel=" | sed "s|^|cfg$i round$round [$cfg] |" >> $out
   done
 done
 python3 - "$out" <<'PY'

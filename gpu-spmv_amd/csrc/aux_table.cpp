@@ -10,6 +10,8 @@
 
 #include <cstdlib>
 
+#include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <unordered_map>
 
@@ -98,6 +100,38 @@ void PrWorkspace::release() {
     if (pinned_ranks) (void)hipHostFree(pinned_ranks);
     for (hipEvent_t e : seen) if (e) (void)hipEventDestroy(e);
     *this = PrWorkspace();
+}
+
+bool debug_option(const char* key, long long* value, char* text, size_t text_size) {
+    return list_option(std::getenv("SPMV_DEBUG"), key, value, text, text_size);
+}
+
+bool list_option(const char* env, const char* key, long long* value, char* text, size_t text_size) {
+    if (!env || !*env) return false;
+    const size_t klen = std::strlen(key);
+    for (const char* p = env; *p;) {
+        const char* end = std::strchr(p, ',');
+        const size_t len = end ? static_cast<size_t>(end - p) : std::strlen(p);
+        if (len >= klen && std::strncmp(p, key, klen) == 0 && (len == klen || p[klen] == '=')) {
+            const char* v = len > klen ? p + klen + 1 : "";
+            const size_t vlen = len > klen ? len - klen - 1 : 0;
+            if (value) *value = vlen ? std::atoll(v) : 1;
+            if (text && text_size) {
+                const size_t n = std::min(vlen, text_size - 1);
+                std::memcpy(text, v, n);
+                text[n] = '\0';
+            }
+            return true;
+        }
+        if (!end) break;
+        p = end + 1;
+    }
+    return false;
+}
+
+bool debug_is(const char* key, const char* expected) {
+    char text[32];
+    return debug_option(key, nullptr, text, sizeof(text)) && std::strcmp(text, expected) == 0;
 }
 
 CsrAux* aux_lookup(const void* key, bool create) {

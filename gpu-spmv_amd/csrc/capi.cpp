@@ -306,7 +306,7 @@ int spmv_c_csr_tiled_info(const spmv_c_csr* A_c, int64_t out[8]) {
     detail::CsrAux* aux = detail::aux_lookup(A->d_row_ptrs, false);
     if (!aux || !aux->tiled) return 0;
     const detail::TiledPlan& p = *aux->tiled;
-    const int64_t v[8] = {p.strip_cols, p.tile_rows, p.num_strips, p.num_tiles, p.nnz, p.num_long, p.lane_entries,
+    const int64_t v[8] = {p.strip_cols, p.tile_rows, p.num_strips, p.num_tiles, p.nnz, p.num_long, 4 /* slots per lane per phase-2 pass */,
                           p.long_row};
     std::memcpy(out, v, sizeof(v));
     return 1;

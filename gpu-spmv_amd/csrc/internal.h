@@ -111,6 +111,25 @@ PlanRef tiled_plan_for(const ELLMatrix* A, hipStream_t s);
 EllAux* ell_aux_lookup(const void* key, bool create);
 void    ell_aux_drop(const void* key);
 
+// ---- debugging / tuning overrides: ONE environment variable ----
+// SPMV_DEBUG="key=value,key,..." (read at every use: tests change it between plan builds).  Keys:
+//   min_cols=N, min_nnz=N      size thresholds of the LDS-tiled engine (tests push small matrices through it)
+//   strip=W, tile=R, item=N    plan shape overrides: strip columns (4096..32768), tile rows (multiple of 64), slots per phase-1 item
+//   long_factor=N, long_cap=N  long-row limit = min(long_cap, long_factor * strips)
+//   rank=plain                 ranking pass of the plan build by comparison (no stable binning)
+//   place=scattered            placing pass of the plan build entry by entry (no LDS staging)
+//   pr_plan_after=N            direct steps pagerank() takes before it builds a plan (default 4)
+//   pr_copy=pageable           pagerank() copies its result into a pageable array (no pinned pool)
+// Everything else the library reads from the environment is listed in INTEGRATION.md.
+bool debug_option(const char* key, long long* value = nullptr, char* text = nullptr, size_t text_size = 0);
+// the same "key=value,key" syntax for another variable's value (SPMV_MULTI_GPU); `list` may be null
+bool list_option(const char* list, const char* key, long long* value = nullptr, char* text = nullptr, size_t text_size = 0);
+inline long long debug_number(const char* key, long long fallback) {
+    long long v = 0;
+    return debug_option(key, &v) ? v : fallback;
+}
+bool debug_is(const char* key, const char* expected);
+
 // ---- launch layer (kernels.hip) ----
 // All return hipError_t from the launch; none synchronise.
 hipError_t launch_csr_scalar(const CSRMatrix* A, const float* d_x, float* d_y, hipStream_t s);

@@ -640,7 +640,7 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
     int build_plan_at = -1;
     if (!plan && !ws.is_private() && detail::tiled_eligible(adj)) {
         build_plan_at = static_cast<int>(std::ceil(34.0 / (17.0 - 3.3))) + 1;        // = 4 direct steps
-        if (const char* env = std::getenv("SPMV_PR_PLAN_AFTER")) build_plan_at = std::max(0, std::atoi(env));
+        build_plan_at = static_cast<int>(std::max(0LL, detail::debug_number("pr_plan_after", build_plan_at)));
         if (build_plan_at == 0) plan = detail::tiled_plan_for(adj, stream);
     }
 
@@ -765,11 +765,8 @@ PageRankResult pagerank(const CSRMatrix* adj, const PageRankConfig* config) {
         float* last = bufs[host_state.iterations & 1];
         ok = detail::pr_normalise(last, static_cast<size_t>(n), ws->partials, stream) == hipSuccess;
         // copy out: device -> pinned staging at PCIe rate, then into the caller's (pageable, freshly
-        // allocated) array; SPMV_PR_COPY=direct hands the pageable array to the runtime instead
-        static const bool direct_copy = [] {
-            const char* env = std::getenv("SPMV_PR_COPY");
-            return env && env[0] == 'd';
-        }();
+        // allocated) array; SPMV_DEBUG=pr_copy=direct hands the pageable array to the runtime instead
+        const bool direct_copy = detail::debug_is("pr_copy", "direct");
         const size_t bytes = static_cast<size_t>(n) * sizeof(float);
         if (ok && (direct_copy || pinned_result)) {
             ok = hipMemcpyAsync(result.ranks, last, bytes, hipMemcpyDeviceToHost, stream) == hipSuccess

@@ -14,7 +14,7 @@
 //     same pr_step the single-GPU loop runs), then ONE in-place ncclAllGather of `stride` floats per device
 //     over xGMI (RCCL, single-process ncclCommInitAll, one stream per device), then pr_commit_gathered folds
 //     the P partial pairs in device order — identical state on every device, no separate all-reduce;
-//   * SPMV_MULTI_GPU_BLOCKS=C > 1: the overlapped exchange — the vector is numbered chunk-major (block c =
+//   * SPMV_MULTI_GPU=blocks=C, C > 1: the overlapped exchange — the vector is numbered chunk-major (block c =
 //     piece c of every shard), C all-gathers per step run on a side stream and the tiled engine's phase 1 of
 //     the NEXT step follows them block by block (pr_expand);
 //   * one host thread per device drives its stream (issuing for eight devices from one thread would take about as
@@ -24,8 +24,8 @@
 //
 // librccl is loaded lazily (dlopen) so that the library itself has no hard dependency on it; with
 // num_gpus == 1 the exchange degenerates to nothing and RCCL is not touched unless
-// SPMV_MULTI_GPU_FORCE_RCCL is set (the single-GPU test box exercises the collective path that way).
-// SPMV_MULTI_GPU_SHARE_DEVICES=1 lets more shards than devices run (shard p on device p % available) with the
+// SPMV_MULTI_GPU=force_rccl is set (the single-GPU test box exercises the collective path that way).
+// SPMV_MULTI_GPU=share_devices lets more shards than devices run (shard p on device p % available) with the
 // slices exchanged by event-ordered device-to-device copies instead of RCCL — RCCL cannot put two ranks on one
 // device; this is how the P > 1 partition, layout and commit are tested on a one-GPU box.
 #include "internal.h"
@@ -198,7 +198,11 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
         return n <= 0 || num_gpus < 1 ? pagerank(adj, config) : result;
     }
     int available = 0;
-    const bool share_devices = std::getenv("SPMV_MULTI_GPU_SHARE_DEVICES") != nullptr;
+    // SPMV_MULTI_GPU="blocks=C,share_devices,force_rccl" — blocks: the overlapped exchange (below); share_devices: more shards
+    // than devices (exchange by device copies: how P > 1 is tested on a one-GPU box); force_rccl: keep the collective in the
+    // loop with ONE shard (the RCCL call itself on a one-GPU box)
+    const char* options = std::getenv("SPMV_MULTI_GPU");
+    const bool share_devices = detail::list_option(options, "share_devices");
     if (hipGetDeviceCount(&available) != hipSuccess || available < 1 || (available < num_gpus && !share_devices)) {
         (void)hipGetLastError();
         return result;
@@ -208,7 +212,7 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
     (void)hipGetDevice(&previous_device);
 
     const int P = num_gpus;
-    const bool force_rccl = std::getenv("SPMV_MULTI_GPU_FORCE_RCCL") != nullptr;
+    const bool force_rccl = detail::list_option(options, "force_rccl");
     const bool exchange = P > 1 || force_rccl;
     const Rccl* api = exchange && !by_copies ? &rccl() : nullptr;
     if (api && !api->ok) {
@@ -223,10 +227,13 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
     if (longest % 2) ++longest;                                  // 8-byte aligned tails
     // The vector is a sequence of `blocks` blocks, block c = piece c of every shard back to back (see RowMap in
     // pagerank_engine.h and Layout in pagerank_dist.py).  One block (default): every shard's slice is contiguous,
-    // one all-gather per step.  SPMV_MULTI_GPU_BLOCKS=C > 1: the overlapped exchange — C all-gathers on a side
+    // one all-gather per step.  SPMV_MULTI_GPU=blocks=C, C > 1: the overlapped exchange — C all-gathers on a side
     // stream, the next step's phase 1 for the columns of block c runs while block c + 1 is on the links.
     int blocks = 1;
-    if (const char* env = std::getenv("SPMV_MULTI_GPU_BLOCKS")) blocks = std::max(1, std::min(16, std::atoi(env)));
+    {
+        long long wanted = 1;
+        if (detail::list_option(options, "blocks", &wanted)) blocks = static_cast<int>(std::max(1LL, std::min(16LL, wanted)));
+    }
     if (!exchange) blocks = 1;
     const int tail = exchange ? kTail : 0;
     long long piece = longest + tail;
@@ -383,7 +390,7 @@ PageRankResult pagerank_multi_gpu(const CSRMatrix* adj, const PageRankConfig* co
                 fine = detail::pr_reduce_commit(d.shard, config->tolerance, d.stream) == hipSuccess;
             }
             if (fine && exchange) {
-                // The exchange: block by block (one block unless SPMV_MULTI_GPU_BLOCKS), on the side stream when
+                // The exchange: block by block (one block unless SPMV_MULTI_GPU=blocks=C), on the side stream when
                 // there are several, so that this stream can multiply block c while block c + 1 travels.
                 const bool side = blocks > 1;
                 hipStream_t xs = side ? d.side_stream : d.stream;

@@ -26,7 +26,6 @@ struct TiledPlan {
     int strip_cols = 0;             // W: x columns per LDS strip
     int tile_rows = 0;              // R: y rows per LDS tile
     int num_strips = 0, num_tiles = 0;
-    int lane_entries = 4;           // slots per lane per phase-2 load (2 for short runs, else 4)
 
     // slots sorted by cell (strip-major, tile inside a strip); inside a cell by (row, column).
     // Every cell's length is a multiple of 4 slots.

@@ -96,9 +96,15 @@ __device__ __forceinline__ T stream_load(const T* p) {
     if constexpr ((SPMV_NT_MASK & BIT) != 0) return __builtin_nontemporal_load(p);
     else return *p;
 }
+#ifndef SPMV_STORE_ASM
+#define SPMV_STORE_ASM 0        // 1: sc1, 2: sc1 nt, 3: sc0 sc1 (16-byte product stores by inline asm)
+#endif
 template <int BIT, typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) {
-    if constexpr ((SPMV_NT_MASK & BIT) != 0) __builtin_nontemporal_store(v, p);
+    if constexpr (SPMV_STORE_ASM == 1 && sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+    else if constexpr (SPMV_STORE_ASM == 2 && sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p), "v"(v) : "memory");
+    else if constexpr (SPMV_STORE_ASM == 3 && sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+    else if constexpr ((SPMV_NT_MASK & BIT) != 0) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 
@@ -158,7 +164,7 @@ struct EllSource {
 struct BuildShape {
     int num_rows, num_tiles, num_strips, strip_shift, tile_rows, long_row;
     int any_long;               // some row is longer than long_row (then every entry's row length is checked)
-    int stable_bins;            // the ranking pass may bin stably (no ranking loop); 0: always rank by comparison (SPMV_TILED_RANK=plain)
+    int stable_bins;            // the ranking pass may bin stably (no ranking loop); 0: always rank by comparison (SPMV_DEBUG=rank=plain)
     long long quota;            // entries per batch before the next one starts
 };
 
@@ -1243,206 +1249,24 @@ struct LongSeeds {
     const float* chunk_sum;   // [num_chunks] written by phase 1 of this SpMV
 };
 
-// Fills the LDS tile with the sums of this tile's rows; the long rows' sums come from their chunk sums.  The tile accumulates in DOUBLE: every fp32 product is added
-// exactly as often as fp64 allows (products of one row rarely span more than 29 binades), so the row
-// sums no longer depend on the order in which the wavefronts' adds meet, and they are rounded to
-// fp32 once, on the way out.
-// E = slots per lane per load (4: 16-byte product + 4-byte delta loads; 2 for matrices with short runs).
-template <int kReduceBlock, int E, int kRuns>
-__device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_index, int num_strips, int num_rows,
-                                                const int2* __restrict__ cells_t,
-                                                const float* __restrict__ prod,
-                                                const unsigned char* __restrict__ a_drow,
-                                                const LongSeeds seeds) {
-    __shared__ double spare[64];           // where a lane's slots without an entry "add" (never read)
-    const long long first = static_cast<long long>(tile_index) * R;
-    for (int i = threadIdx.x; i < R; i += kReduceBlock) tile[i] = 0.0;
-    if (seeds.tile_first) {
-        __syncthreads();
-        for (int k = seeds.tile_first[tile_index] + threadIdx.x; k < seeds.tile_first[tile_index + 1]; k += kReduceBlock) {
-            double total = 0.0;                         // a long row's chunk sums, in chunk order
-            for (int c = seeds.first_chunk[k]; c < seeds.first_chunk[k + 1]; ++c) total += static_cast<double>(seeds.chunk_sum[c]);
-            tile[seeds.rows[k] - first] = total;
-        }
-    }
-    __syncthreads();
-
-    typedef float prod_t __attribute__((ext_vector_type(E)));
-    typedef unsigned int delta_word_t;
-    constexpr int kWords = (E + 3) / 4;
-    // (phase 2 is bound by vector-instruction issue once its loads are wide: rocprofv3 counted ~160 VALU
-    // instructions per 128-slot run chunk in a first version, 85 % of the kernel's cycles.  Hence: run
-    // geometry kept in scalar registers (v_readlane, not ds_bpermute), addresses as scalar base + one shared
-    // 32-bit lane offset, no per-run branches around the loads (out-of-run lanes re-read the run's last
-    // group and are masked afterwards), two pass records used alternately instead of copied.)
-    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    const unsigned int lane = threadIdx.x & 63;
-    constexpr int kWaves = kReduceBlock / 64;
-    static_assert(64 % kRuns == 0, "a group of runs never straddles two 64-run windows of the cell table");
-    // Every wavefront owns a contiguous share of the tile's runs (one run per strip) and walks it in groups
-    // of kRuns runs, one chunk of 64 * E slots from each run per PASS.  Passes are software-pipelined: the
-    // loads of pass n + 1 (16- or 8-byte products, 4- or 2-byte deltas) are issued before pass n's products
-    // go into the LDS tile.  A run's rows are rebuilt from its deltas: in-lane prefix over the lane's E
-    // slots, one wavefront scan over the lanes' totals, plus the row the run's previous chunk ended at.
-    const int per_wave = (num_strips + kWaves - 1) / kWaves;
-    const int run_lo = min(num_strips, wave * per_wave), run_hi = min(num_strips, run_lo + per_wave);
-    const int2* mine = cells_t + static_cast<long long>(tile_index) * num_strips;
-    // window of 64 (begin, length) records, lane l holds run window_first + l; the next window is fetched early
-    int window_first = run_lo;
-    int2 window = run_lo + static_cast<int>(lane) < run_hi ? mine[run_lo + lane] : make_int2(0, 0);
-    int2 window_ahead = run_lo + 64 + static_cast<int>(lane) < run_hi ? mine[run_lo + 64 + lane] : make_int2(0, 0);
-
-    struct Pass {
-        int begin[kRuns], len[kRuns];      // wave-uniform; len: a multiple of 4 slots
-        int done, longest;                 // wave-uniform
-        bool valid;
-        prod_t p[kRuns];
-        delta_word_t d[kRuns][kWords];     // E delta bytes (E = 2: the low half of one word)
-    };
-    int group = run_lo;                    // first run of the group opened next
-    auto open_group = [&](Pass& ps) {
-        ps.valid = group < run_hi;
-        ps.done = 0;
-        ps.longest = 0;
-        if (!ps.valid) return;
-        if (group >= window_first + 64) {
-            window_first += 64;
-            window = window_ahead;
-            window_ahead = window_first + 64 + static_cast<int>(lane) < run_hi ? mine[window_first + 64 + lane]
-                                                                              : make_int2(0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < kRuns; ++j) {
-            const int k = min(group + j - window_first, 63);
-            ps.begin[j] = __builtin_amdgcn_readlane(window.x, k);
-#if defined(SPMV_PROBE_PHASE2) && SPMV_PROBE_PHASE2 == 3      // timing probe: as if products and deltas were stored TILE-major (a tile's runs
-            ps.begin[j] = (tile_index * num_strips + min(group + j, num_strips - 1)) * 256;     // back to back, 256-slot pitch; C5 only; results wrong)
-#endif
-            ps.len[j] = group + j < run_hi ? __builtin_amdgcn_readlane(window.y, k) : 0;
-            ps.longest = max(ps.longest, ps.len[j]);
-        }
-        group += kRuns;
-    };
-    auto next_pass = [&](Pass& to, const Pass& from) {
-        to.valid = true;
-        to.done = from.done + 64 * E;
-        to.longest = from.longest;
-#pragma unroll
-        for (int j = 0; j < kRuns; ++j) {
-            to.begin[j] = from.begin[j];
-            to.len[j] = from.len[j];
-        }
-        if (to.done >= from.longest) open_group(to);
-    };
-    auto issue_loads = [&](Pass& ps) {
-        const unsigned int i = static_cast<unsigned int>(ps.done) + E * lane;
-#pragma unroll
-        for (int j = 0; j < kRuns; ++j) {
-            // lanes past the run's end re-read its last 4 (E = 2: 2) slots (same cache line, no extra traffic) and a lane
-            // that straddles the end (E = 8, length 4 mod 8) reads 4 slots of the next cell: both masked below
-            const unsigned int last = static_cast<unsigned int>(max(ps.len[j] - (E < 4 ? E : 4), 0));
-            const unsigned int at = min(i, last);
-            const char* products = reinterpret_cast<const char*>(prod + ps.begin[j]);
-            const char* deltas = reinterpret_cast<const char*>(a_drow + ps.begin[j]);
-            ps.p[j] = *reinterpret_cast<const prod_t*>(products + static_cast<size_t>(at << 2));
-            if (E == 2) {
-                ps.d[j][0] = *reinterpret_cast<const unsigned short*>(deltas + static_cast<size_t>(at));
-            } else {
-#pragma unroll
-                for (int w = 0; w < kWords; ++w) {
-                    ps.d[j][w] = *reinterpret_cast<const unsigned int*>(deltas + static_cast<size_t>(at) + 4 * w);
-                }
-            }
-        }
-    };
-
-    int row_base[kRuns];                   // wave-uniform: row the run's previous chunk ended at
-#if defined(SPMV_PROBE_PHASE2)
-    float probe_sum = 0.f;
-#endif
-    auto process = [&](const Pass& ps) {
-        const unsigned int i = static_cast<unsigned int>(ps.done) + E * lane;
-#pragma unroll
-        for (int j = 0; j < kRuns; ++j) {
-            if (ps.done == 0) row_base[j] = 0;
-            if (ps.done >= ps.len[j]) continue;             // wave-uniform
-            // slots past the run's end become skip markers (the run ends in this chunk, so what they add to
-            // the scan is never used): whole words, since lengths and lane offsets are multiples of 4 (E >= 4)
-            unsigned int word[kWords];
-#pragma unroll
-            for (int w = 0; w < kWords; ++w) {
-                word[w] = i + 4 * w < static_cast<unsigned int>(ps.len[j]) ? ps.d[j][w] : 0xFFFFFFFFu;
-            }
-            int delta[E], upto[E];
-            int sum = 0;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                delta[e] = (word[e / 4] >> (8 * (e % 4))) & 0xFF;
-                sum += delta[e];
-                upto[e] = sum;
-            }
-            const int incl = wave_inclusive_scan(sum);
-            const int lane_base = row_base[j] + incl - sum;
-            row_base[j] += __builtin_amdgcn_readlane(incl, 63);
-            // One LDS atomic per slot: ds_add_f64 (no return value, no retry loop, equal rows in one
-            // instruction are the hardware's business; gfx950 runs it at 3.5 lanes/clk/CU on random rows,
-            // the fp32 form at 0.38 — tools/lds_bench.hip).  Skip markers aim at a per-lane spare word, so
-            // nothing here needs an execution mask.
-#if defined(SPMV_PROBE_PHASE2) && SPMV_PROBE_PHASE2 == 1      // timing probe: plain LDS stores where the adds go (results wrong)
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                double* target = delta[e] != kSkip ? &tile[lane_base + upto[e]] : &spare[lane];
-                *reinterpret_cast<volatile double*>(target) = static_cast<double>(ps.p[j][e]);
-            }
-#elif defined(SPMV_PROBE_PHASE2) && SPMV_PROBE_PHASE2 == 2    // timing probe: no LDS traffic for the adds (results wrong)
-            {
-#pragma unroll
-                for (int e = 0; e < E; ++e) probe_sum += ps.p[j][e] * static_cast<float>(lane_base + upto[e]);
-            }
-#else
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                double* target = delta[e] != kSkip ? &tile[lane_base + upto[e]] : &spare[lane];
-                atomicAdd(target, static_cast<double>(ps.p[j][e]));
-            }
-#endif
-        }
-    };
-
-    Pass a, b;
-    open_group(a);
-    if (a.valid) issue_loads(a);
-    while (a.valid) {
-        next_pass(b, a);
-        if (b.valid) issue_loads(b);
-        process(a);
-        if (!b.valid) break;
-        next_pass(a, b);
-        if (a.valid) issue_loads(a);
-        process(b);
-    }
-#if defined(SPMV_PROBE_PHASE2)
-    tile[threadIdx.x] += static_cast<double>(probe_sum);
-#endif
-    __syncthreads();
-}
-
 #ifndef SPMV_STREAM_DEPTH
 #define SPMV_STREAM_DEPTH 2
 #endif
 #ifndef SPMV_STREAM_SEGS
 #define SPMV_STREAM_SEGS 3      // segments per pass: 2 / 3 / 4 measured 492 / 482 / 483 us on C5, 47.9 / 48.7 / 51.9 on C2, 41.6 / 42.4 / 44.2 on C4
 #endif
-// STREAM form of the same accumulation (round 3).  Phase 2 is bound by vector-instruction issue, not by its loads
-// or its LDS adds (profiles/r03_phase2_probes.txt: the kernel without any LDS traffic for the adds runs in 197 us
-// instead of 208, reading a tile's runs back to back instead of one per strip in 193-197 us; 78 M wave64 VALU
-// instructions x 4 cycles = 145 us per SIMD).  A third of the passes of the run-by-run form are tails: runs average
-// 258 slots on C5 and a pass takes 256.  Here the runs a wavefront owns are ONE stream of slots, 256 per pass whatever
-// the run boundaries: a pass is up to kSegs SEGMENTS (the end of one run, whole short runs, the start of the next),
-// every lane picks its segment's base by comparing its lane number with the segments' first lanes, the row of a slot
-// is its wave-wide prefix sum minus the prefix sum at the end of the previous segment (read with v_readlane: the
-// boundaries are wave-uniform), and the run that continues into the next pass carries its row over in a scalar.
-// Same slots, same rows, same fp64 adds: bit-identical results.
+// Fills the LDS tile with the sums of this tile's rows; the long rows' sums come from their chunk sums.  The tile
+// accumulates in DOUBLE: every fp32 product is added exactly as often as fp64 allows (products of one row rarely span
+// more than 29 binades), so the row sums do not depend on the order in which the wavefronts' adds meet, and they are
+// rounded to fp32 once, on the way out.
+// The runs a wavefront owns (one per strip, a contiguous share of the strips) are walked as ONE stream of slots, 256 per
+// pass whatever the run boundaries (round 3; the run-by-run walk it replaced spent a third of its passes on run tails —
+// profiles/r03_phase2_probes.txt — and was retired in round 4): a pass is up to kSegs SEGMENTS (the end of one run, whole
+// short runs, the start of the next), every lane picks its segment's base by comparing its lane number with the
+// segments' first lanes, the row of a slot is its wave-wide prefix sum of the row deltas minus the prefix sum at the end
+// of the previous segment (read with v_readlane: the boundaries are wave-uniform), and the run that continues into the
+// next pass carries its row over in a scalar.  Run geometry lives in scalar registers, addresses are a scalar base + one
+// shared lane offset, and passes are software-pipelined (the next passes' loads are in flight while this one adds).
 template <int kReduceBlock, int kSegs>
 __device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int tile_index, int num_strips, int num_rows,
                                                        const int2* __restrict__ cells_t,
@@ -1483,6 +1307,11 @@ __device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int 
     int row_carry = 0;                     // wave-uniform: the row the open run has reached (0 at a run's start)
 #if defined(SPMV_PROBE_P2)
     float probe_acc = 0.f;
+    int probe_pass = 0;
+    // (all slots of the plan: the end of the last cell, rounded down so that a lane's 16-byte load stays inside)
+    const int probe_tiles = (num_rows + R - 1) / R;
+    const int2 probe_last = cells_t[static_cast<long long>(probe_tiles) * num_strips - 1];
+    const long long probe_slots = max(256, (probe_last.x + probe_last.y) / 256 * 256);
 #endif
 
     // The (begin, length) records of the wavefront's runs come 64 at a time (lane l holds run window_first + l); inside
@@ -1530,12 +1359,19 @@ __device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int 
             int base = ps.valid ? ps.base[0] : 0;
 #pragma unroll
             for (int k = 1; k < kSegs; ++k) base = at >= ps.start[k] && ps.valid ? ps.base[k] : base;
-            const unsigned int slot = static_cast<unsigned int>(base + 4 * at);
+            unsigned int slot = static_cast<unsigned int>(base + 4 * at);
+#if defined(SPMV_PROBE_P2) && (SPMV_PROBE_P2 == 14 || SPMV_PROBE_P2 == 15)      // timing probes (with the loads-only body): every wavefront reads ONE contiguous range
+            slot = static_cast<unsigned int>((((static_cast<long long>(tile_index) * kWaves + wave) * 48 + (probe_pass++ % 48)) * 256 + 4 * lane) % probe_slots);
+#endif
             ps.p = stream_load<4>(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(prod) + (static_cast<size_t>(slot) << 2)));
+#if defined(SPMV_PROBE_P2) && (SPMV_PROBE_P2 == 13 || SPMV_PROBE_P2 == 15 || SPMV_PROBE_P2 == 17)    // ... without the 4-byte delta load
+            ps.d = slot;
+#else
             ps.d = stream_load<4>(reinterpret_cast<const unsigned int*>(a_drow + slot));
+#endif
         };
         auto process = [&](const Pass& ps) {
-#if defined(SPMV_PROBE_P2) && SPMV_PROBE_P2 == 10       // timing probe: loads only (no decode, no LDS adds); results wrong
+#if defined(SPMV_PROBE_P2) && (SPMV_PROBE_P2 == 10 || SPMV_PROBE_P2 >= 13)       // timing probe: loads only (no decode, no LDS adds); results wrong
             probe_acc += ps.p[0] + ps.p[1] + ps.p[2] + ps.p[3] + __uint_as_float(ps.d);
             return;
 #elif defined(SPMV_PROBE_P2) && SPMV_PROBE_P2 == 12     // timing probe: loads + LDS adds, rows without any decode; results wrong
@@ -1603,8 +1439,8 @@ __device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int 
 }
 
 // The tile (R doubles, R = plan.tile_rows: any multiple of 64) lives in dynamic LDS.
-template <int kReduceBlock, int E, int kRuns>
-__global__ __launch_bounds__(kReduceBlock, kReduceBlock / 128)     // two tiles per CU: 8 (1024 threads) or 4 wavefronts per SIMD
+template <int kReduceBlock>
+__global__ __launch_bounds__(kReduceBlock, kReduceBlock / 128)     // two tiles per CU: 8 wavefronts per SIMD
 void tiled_reduce_kernel(int R, int first_tile, int num_tiles, const int2* __restrict__ cells_t, int num_strips,
                          const float* __restrict__ prod,
                          const unsigned char* __restrict__ a_drow,
@@ -1614,14 +1450,13 @@ void tiled_reduce_kernel(int R, int first_tile, int num_tiles, const int2* __res
     const int window = xcd_contiguous(blockIdx.x, num_tiles);
     if (window < 0) return;
     const int tile_index = first_tile + window;
-    if constexpr (kRuns == 0) tile_accumulate_stream<kReduceBlock, SPMV_STREAM_SEGS>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_drow, seeds);
-    else tile_accumulate<kReduceBlock, E, kRuns>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_drow, seeds);
+    tile_accumulate_stream<kReduceBlock, SPMV_STREAM_SEGS>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_drow, seeds);
     const long long first = static_cast<long long>(tile_index) * R;
     for (int i = threadIdx.x; i < R && first + i < num_rows; i += kReduceBlock) y[first + i] = static_cast<float>(tile[i]);
 }
 
 // phase 2 with the PageRank update fused into the tile write-out (cf. pr_step_kernel)
-template <int kReduceBlock, int E, int kRuns>
+template <int kReduceBlock>
 __global__ __launch_bounds__(kReduceBlock, kReduceBlock / 128)
 void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__ cells_t, int num_strips,
                                   const float* __restrict__ prod,
@@ -1636,8 +1471,7 @@ void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__
     extern __shared__ double tile[];
     const int tile_index = xcd_contiguous(blockIdx.x, num_tiles);
     if (tile_index < 0) return;
-    if constexpr (kRuns == 0) tile_accumulate_stream<kReduceBlock, SPMV_STREAM_SEGS>(tile, R, tile_index, num_strips, local_rows, cells_t, prod, a_drow, seeds);
-    else tile_accumulate<kReduceBlock, E, kRuns>(tile, R, tile_index, num_strips, local_rows, cells_t, prod, a_drow, seeds);
+    tile_accumulate_stream<kReduceBlock, SPMV_STREAM_SEGS>(tile, R, tile_index, num_strips, local_rows, cells_t, prod, a_drow, seeds);
 
     const float teleport = __fdiv_rn(1.0f - damping, static_cast<float>(n_global));
     const float dangling_term = __fdiv_rn(__fmul_rn(damping, state->dangling_sum),
@@ -1711,13 +1545,11 @@ void choose_shape(long long num_rows, long long num_cols, long long nnz, int* st
         while (narrower < w && nnz / (strips_for(narrower) * tiles_for(r)) < kComfortableRun) narrower <<= 1;
         w = narrower;
     }
-    if (const char* env = std::getenv("SPMV_TILED_STRIP")) {
-        const int v = std::atoi(env);
-        if (v == 4096 || v == 8192 || v == 16384 || v == 32768) w = v;
-    }
-    if (const char* env = std::getenv("SPMV_TILED_TILE")) {
-        const int v = std::atoi(env);
-        if (v >= 64 && v <= 15360 && v % 64 == 0) r = v;
+    {   // SPMV_DEBUG=strip=W,tile=R: shape overrides for experiments and boundary-case tests
+        const long long v = debug_number("strip", 0);
+        if (v == 4096 || v == 8192 || v == 16384 || v == 32768) w = static_cast<int>(v);
+        const long long t = debug_number("tile", 0);
+        if (t >= 64 && t <= kMaxTileRows && t % 64 == 0) r = static_cast<int>(t);
     }
     *strip_cols = w;
     *tile_rows = r;
@@ -1793,49 +1625,21 @@ LongSeeds long_seeds(const TiledPlan& plan, const Scratch& sc) {
     return LongSeeds{plan.long_rows, plan.long_first, plan.num_long > 0 ? plan.tile_long : nullptr, sc.long_sums};
 }
 
-template <int BLOCK, int E, int kRuns>
-hipError_t launch_reduce_as(const TiledPlan& plan, const Scratch& sc, int first_tile, int num_tiles, float* d_y, hipStream_t s) {
-    const size_t lds = static_cast<size_t>(plan.tile_rows) * sizeof(double);
-    const void* kernel = reinterpret_cast<const void*>(&tiled_reduce_kernel<BLOCK, E, kRuns>);
-    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return e;
-    tiled_reduce_kernel<BLOCK, E, kRuns><<<xcd_grid(num_tiles), BLOCK, lds, s>>>(
-        plan.tile_rows, first_tile, num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, sc.prod, plan.a_drow,
-        long_seeds(plan, sc), plan.num_rows, d_y);
-    return hipGetLastError();
-}
-
-// SPMV_TILED_STREAM=0 brings the run-by-run form of phase 2 back (A/B runs)
-bool stream_form() {
-    static const bool on = [] {
-        const char* env = std::getenv("SPMV_TILED_STREAM");
-        return !(env && env[0] == '0');
-    }();
-    return on;
-}
+constexpr int kReduceThreads = 1024;
 
 hipError_t launch_reduce(const TiledPlan& plan, const Scratch& sc, int first_tile, int num_tiles, float* d_y, hipStream_t s) {
-    if (stream_form()) return launch_reduce_as<1024, 4, 0>(plan, sc, first_tile, num_tiles, d_y, s);
-    switch (plan.lane_entries) {
-        case 2:  return launch_reduce_as<1024, 2, 4>(plan, sc, first_tile, num_tiles, d_y, s);
-        case 4:  return launch_reduce_as<1024, 4, 2>(plan, sc, first_tile, num_tiles, d_y, s);
-        default: return launch_reduce_as<1024, 8, 1>(plan, sc, first_tile, num_tiles, d_y, s);
-    }
-}
-
-template <int BLOCK, int E, int kRuns>
-hipError_t launch_pagerank_reduce_as(const TiledPlan& plan, const Scratch& sc, const RowMap& map, int n_global, const float* d_r_old,
-                                     float* d_r_new, const unsigned char* d_dangling, float damping,
-                                     const PrState* d_state, double* d_block_partials,
-                                     const PushTargets& push, hipStream_t s) {
     const size_t lds = static_cast<size_t>(plan.tile_rows) * sizeof(double);
-    const void* kernel = reinterpret_cast<const void*>(&tiled_pagerank_reduce_kernel<BLOCK, E, kRuns>);
+    const void* kernel = reinterpret_cast<const void*>(&tiled_reduce_kernel<kReduceThreads>);
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
-    tiled_pagerank_reduce_kernel<BLOCK, E, kRuns><<<xcd_grid(plan.num_tiles), BLOCK, lds, s>>>(
-        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, sc.prod, plan.a_drow,
-        long_seeds(plan, sc), plan.num_rows, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
-        d_block_partials, push);
+#if defined(SPMV_PROBE_P2) && SPMV_PROBE_P2 >= 16       // timing probe: phase 2 reads the VALUE array (same size, not freshly written) in place of the products
+    const float* probe_source = plan.a_val ? plan.a_val : sc.prod;
+#else
+    const float* probe_source = sc.prod;
+#endif
+    tiled_reduce_kernel<kReduceThreads><<<xcd_grid(num_tiles), kReduceThreads, lds, s>>>(
+        plan.tile_rows, first_tile, num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, probe_source, plan.a_drow,
+        long_seeds(plan, sc), plan.num_rows, d_y);
     return hipGetLastError();
 }
 
@@ -1843,16 +1647,15 @@ hipError_t launch_pagerank_reduce(const TiledPlan& plan, const Scratch& sc, cons
                                   float* d_r_new, const unsigned char* d_dangling, float damping,
                                   const PrState* d_state, double* d_block_partials,
                                   const PushTargets& push, hipStream_t s) {
-#define SPMV_PR_REDUCE(BLOCK, E, RUNS) \
-    launch_pagerank_reduce_as<BLOCK, E, RUNS>(plan, sc, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state, \
-                                              d_block_partials, push, s)
-    if (stream_form()) return SPMV_PR_REDUCE(1024, 4, 0);
-    switch (plan.lane_entries) {
-        case 2:  return SPMV_PR_REDUCE(1024, 2, 4);
-        case 4:  return SPMV_PR_REDUCE(1024, 4, 2);
-        default: return SPMV_PR_REDUCE(1024, 8, 1);
-    }
-#undef SPMV_PR_REDUCE
+    const size_t lds = static_cast<size_t>(plan.tile_rows) * sizeof(double);
+    const void* kernel = reinterpret_cast<const void*>(&tiled_pagerank_reduce_kernel<kReduceThreads>);
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    tiled_pagerank_reduce_kernel<kReduceThreads><<<xcd_grid(plan.num_tiles), kReduceThreads, lds, s>>>(
+        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, sc.prod, plan.a_drow,
+        long_seeds(plan, sc), plan.num_rows, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
+        d_block_partials, push);
+    return hipGetLastError();
 }
 
 } // namespace
@@ -1864,16 +1667,11 @@ bool eligible_dims(long long rows, long long cols, long long nnz) {
         const char* env = std::getenv("SPMV_TILED");
         return !(env && env[0] == '0');
     }();
-    static const long long min_cols = [] {
-        const char* env = std::getenv("SPMV_TILED_MIN_COLS");
-        // measured crossover (tools/quick_bench.py crossover, 1 M rows x 16): 65536 columns tie
-        // (69 vs 71 us), 131072 columns 60 vs 74 us, 262144 columns 57 vs 76 us
-        return env ? std::atoll(env) : 65536LL;
-    }();
-    static const long long min_nnz = [] {
-        const char* env = std::getenv("SPMV_TILED_MIN_NNZ");      // tests force small matrices through the engine
-        return env ? std::atoll(env) : 1LL << 20;
-    }();
+    // measured crossover (tools/quick_bench.py crossover, 1 M rows x 16): 65536 columns tie
+    // (69 vs 71 us), 131072 columns 60 vs 74 us, 262144 columns 57 vs 76 us
+    // (SPMV_DEBUG=min_cols=1,min_nnz=1: tests force small matrices through the engine)
+    const long long min_cols = debug_number("min_cols", 65536LL);
+    const long long min_nnz = debug_number("min_nnz", 1LL << 20);
     if (!enabled || rows <= 0 || nnz < min_nnz || cols < min_cols) return false;
     int w = 0, r = 0;
     choose_shape(rows, cols, nnz, &w, &r);
@@ -2035,7 +1833,7 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     sh.quota = std::max(64, capacity - std::min(longest, plan->long_row));
     sh.any_long = longest > plan->long_row ? 1 : 0;
     sh.stable_bins = 1;
-    if (const char* env = std::getenv("SPMV_TILED_RANK")) sh.stable_bins = std::strcmp(env, "plain") != 0;
+    if (debug_is("rank", "plain")) sh.stable_bins = 0;
 
     tile_batches_kernel<<<(T + kBlock - 1) / kBlock, kBlock, 0, s>>>(dev_src, sh, tile_batch);
     // exclusive scan of the per-tile batch counts (one workgroup: T is at most a few hundred thousand)
@@ -2107,7 +1905,7 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     if (plan->nnz > 0) {
         // staged placing pass (contiguous segments); the batches it cannot hold are flagged for the scattered one
         bool staged = true;
-        if (const char* env = std::getenv("SPMV_TILED_PLACE")) staged = std::strcmp(env, "scattered") != 0;
+        if (debug_is("place", "scattered")) staged = false;
         int* todo = place_todo;
         if (staged) {
             const int stage_slots = (capacity + 1024 + 63) / 64 * 64;
@@ -2170,9 +1968,9 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     // collisions far better (profiles/r02_long_row_sweep.txt, C4 = 1 M power-law rows, 62 strips: limit 124
     // entries 49.5 us, 248: 47.2, 496: 44.2, unlimited 47.8; 10 M x 10 M power-law: 426 / 435 / 416 / 402 us).
     int long_factor = 8;
-    if (const char* env = std::getenv("SPMV_TILED_LONG_FACTOR")) long_factor = std::max(1, std::atoi(env));
+    long_factor = static_cast<int>(std::max(1LL, debug_number("long_factor", long_factor)));
     int long_cap = kMaxLongRow;
-    if (const char* env = std::getenv("SPMV_TILED_LONG_CAP")) long_cap = std::max(64, std::atoi(env));
+    long_cap = static_cast<int>(std::max(64LL, debug_number("long_cap", long_cap)));
     plan->long_row = A ? std::max(64, std::min(long_cap, long_factor * plan->num_strips)) : 0x3fffffff;
 
     auto fail = [&](hipError_t e) {
@@ -2200,19 +1998,6 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         return fail(err);
     };
     if (e != hipSuccess) return fail_with_strip(e);
-    {   // Slots a lane takes per phase-2 pass (a wavefront's pass covers 64 of them from each run): 2, 4 or 8.
-        // Measured on C5 (mean run 258 slots): 205 / 207 / 208 us — phase 2 does not care (the LDS adds,
-        // 160 M ds_add_f64 = ~130 us of LDS pipe, and the 0.85 GB of loads, ~155 us, share the time; neither
-        // the pass count nor the instruction count moved it), so the choice only avoids mostly-empty passes.
-        const double mean_run = static_cast<double>(plan->nnz) / std::max<long long>(cells, 1);
-        const double typical = mean_run + 2.0 * std::sqrt(mean_run);
-        plan->lane_entries = typical <= 128 ? 2 : (typical <= 512 ? 4 : 8);
-        if (const char* env = std::getenv("SPMV_TILED_LANE_ENTRIES")) {
-            const int v = std::atoi(env);
-            if (v == 2 || v == 4 || v == 8) plan->lane_entries = v;
-        }
-    }
-
     if (A && plan->num_long > 0) {
         // cut the long rows into wavefront-sized chunks (the list is short: <= nnz / long_row rows)
         std::vector<int> rows(plan->num_long);
@@ -2328,7 +2113,7 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     const long long floor_entries = std::max<long long>(kMinItemEntries, plan->strip_cols);   // strip load <= 40 % of the stream
     int item_entries = static_cast<int>(std::min<long long>(
         kMaxItemEntries, std::max<long long>(floor_entries, (plan->nnz / 2048 + 7) / 8 * 8)));
-    if (const char* env = std::getenv("SPMV_TILED_ITEM")) item_entries = std::max(1024, std::atoi(env));
+    item_entries = static_cast<int>(std::max(1024LL, debug_number("item", item_entries)));
     std::vector<int> items;
     plan->strip_first_item = new int[static_cast<size_t>(plan->num_strips) + 1];
     for (int strip = 0; strip < plan->num_strips; ++strip) {
@@ -2349,9 +2134,7 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     }
     plan->num_items = static_cast<int>(items.size() / 3);
     plan->strip_first_item[plan->num_strips] = plan->num_items;
-    if (const char* env = std::getenv("SPMV_TILED_PARTS")) {
-        plan->num_parts = std::max(1, std::min({std::atoi(env), 8, plan->num_tiles}));
-    }
+    plan->num_parts = static_cast<int>(std::max(1LL, std::min({debug_number("parts", 1), 32LL, static_cast<long long>(plan->num_tiles)})));
     if (plan->num_parts > 1) {
         const int n = plan->num_parts, S = plan->num_strips;
         std::vector<std::vector<int>> bound(n + 1, std::vector<int>(S));
@@ -2473,6 +2256,16 @@ hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipSt
         }
         const std::vector<int>& fi = plan.part_first_item;
         const std::vector<int>& ft = plan.part_first_tile;
+        if (debug_option("parts_seq")) {
+            // EXPERIMENT: part by part on ONE stream — phase 2 of a part reads its products right behind phase 1
+            // (while they are still in the Infinity Cache)
+            for (int p = 0; p < n; ++p) {
+                e = launch_expand(plan, sc, fi[p], fi[p + 1] - fi[p], p == 0, d_x, nullptr, s);
+                if (e == hipSuccess) e = launch_reduce(plan, sc, ft[p], ft[p + 1] - ft[p], d_y, s);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        }
         e = launch_expand(plan, sc, fi[0], fi[1] - fi[0], true, d_x, nullptr, s);
         for (int p = 1; p < n && e == hipSuccess; ++p) {
             e = hipEventRecord(plan.part_events[p - 1], s);

@@ -5,10 +5,10 @@
 //   multi_gpu_pagerank bounds         CPU only: the equal-nnz row boundaries
 //   multi_gpu_pagerank run [N]        needs N (default 1) GPUs: pagerank_multi_gpu(N) == pagerank() on a uniform
 //                                     and on a power-law graph, plain and through SPMV_NUM_GPUS; with N == 1 the
-//                                     collective path is exercised too (SPMV_MULTI_GPU_FORCE_RCCL), and the P > 1
+//                                     collective path is exercised too (SPMV_MULTI_GPU=force_rccl), and the P > 1
 //                                     partition / layout / commit with 2, 3 and 8 shards sharing the device
-//                                     (SPMV_MULTI_GPU_SHARE_DEVICES: slices exchanged by device copies), also with
-//                                     the overlapped exchange (SPMV_MULTI_GPU_BLOCKS) on a graph large enough for
+//                                     (SPMV_MULTI_GPU=share_devices: slices exchanged by device copies), also with
+//                                     the overlapped exchange (SPMV_MULTI_GPU=blocks=C) on a graph large enough for
 //                                     the tiled engine, whose phase 1 then follows the blocks
 // Plain host C++: g++ -Iinclude ... -lspmv_amd.
 #include "spmv/pagerank.h"
@@ -97,11 +97,10 @@ static void test_blocks() {
     cfg.tolerance = 0.0f;
     PageRankResult single = pagerank(g, &cfg);
     EXPECT(single.ranks && single.iterations == 12);
-    setenv("SPMV_MULTI_GPU_SHARE_DEVICES", "1", 1);
     for (int blocks : {1, 3, 4}) {
-        char text[16];
-        std::snprintf(text, sizeof(text), "%d", blocks);
-        setenv("SPMV_MULTI_GPU_BLOCKS", text, 1);
+        char text[48];
+        std::snprintf(text, sizeof(text), "share_devices,blocks=%d", blocks);
+        setenv("SPMV_MULTI_GPU", text, 1);
         for (int shards : {2, 3}) {
             PageRankResult r = pagerank_multi_gpu(g, &cfg, shards);
             EXPECT(r.ranks != nullptr && r.iterations == 12);
@@ -109,15 +108,12 @@ static void test_blocks() {
             pagerank_free(&r);
         }
     }
-    unsetenv("SPMV_MULTI_GPU_SHARE_DEVICES");
-    setenv("SPMV_MULTI_GPU_FORCE_RCCL", "1", 1);            // RCCL with one rank, two blocks, side stream
-    setenv("SPMV_MULTI_GPU_BLOCKS", "2", 1);
+    setenv("SPMV_MULTI_GPU", "force_rccl,blocks=2", 1);     // RCCL with one rank, two blocks, side stream
     PageRankResult forced = pagerank_multi_gpu(g, &cfg, 1);
     EXPECT(forced.ranks != nullptr && forced.iterations == 12);
     if (forced.ranks) EXPECT(worst_relative(forced, single, n) <= 4e-6);
     pagerank_free(&forced);
-    unsetenv("SPMV_MULTI_GPU_FORCE_RCCL");
-    unsetenv("SPMV_MULTI_GPU_BLOCKS");
+    unsetenv("SPMV_MULTI_GPU");
     pagerank_free(&single);
     csr_destroy(g);
 }
@@ -145,9 +141,9 @@ static void test_run(int gpus) {
             EXPECT(std::fabs(sum - 1.0) < 1e-4);
         }
         if (gpus == 1) {                                    // the collective path on one device
-            setenv("SPMV_MULTI_GPU_FORCE_RCCL", "1", 1);
+            setenv("SPMV_MULTI_GPU", "force_rccl", 1);
             PageRankResult forced = pagerank_multi_gpu(g, &cfg, 1);
-            unsetenv("SPMV_MULTI_GPU_FORCE_RCCL");
+            unsetenv("SPMV_MULTI_GPU");
             EXPECT(forced.ranks != nullptr);
             if (forced.ranks && forced.iterations == single.iterations) EXPECT(worst_relative(forced, single, n) <= 2e-6);
             pagerank_free(&forced);
@@ -162,7 +158,7 @@ static void test_run(int gpus) {
             pagerank_free(&routed);
         }
         if (gpus == 1) {                                    // P > 1 shards on the one device, exchange by copies
-            setenv("SPMV_MULTI_GPU_SHARE_DEVICES", "1", 1);
+            setenv("SPMV_MULTI_GPU", "share_devices", 1);
             for (int shards : {2, 3, 8}) {
                 PageRankResult shared = pagerank_multi_gpu(g, &cfg, shards);
                 EXPECT(shared.ranks != nullptr);
@@ -175,7 +171,7 @@ static void test_run(int gpus) {
                 }
                 pagerank_free(&shared);
             }
-            unsetenv("SPMV_MULTI_GPU_SHARE_DEVICES");
+            unsetenv("SPMV_MULTI_GPU");
         }
         // more devices than the machine has: an empty result, not a crash
         PageRankResult none = pagerank_multi_gpu(g, &cfg, 1024);

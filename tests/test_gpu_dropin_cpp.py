@@ -42,7 +42,7 @@ def test_reference_gtest_cases_restated_in_cpp(gpu):
 def test_native_multi_gpu_pagerank_entry_point(gpu):
     """tests/cpp/multi_gpu_pagerank.cpp: pagerank_multi_gpu(adj, config, 1) — the single-process RCCL host loop
     behind the reference's API (include/spmv/pagerank.h extension) — equals pagerank() on a uniform and on a
-    power-law graph, both without and with the RCCL all-gather in the loop (one device: SPMV_MULTI_GPU_FORCE_RCCL),
+    power-law graph, both without and with the RCCL all-gather in the loop (one device: SPMV_MULTI_GPU=force_rccl),
     and the equal-nnz shard boundaries are right."""
     exe = os.path.join(ROOT, "tests", "cpp", "bin", "multi_gpu_pagerank")
     assert os.path.exists(exe), "run __graft_entry__.build() first"

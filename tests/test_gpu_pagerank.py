@@ -415,14 +415,14 @@ def test_pagerank_through_the_tiled_engine(gpu, oracle):
 
 def test_pagerank_switches_to_the_tiled_engine_mid_run(gpu, oracle):
     """A matrix without a cached plan starts on the direct-gather step and switches to the tiled engine once
-    it has spent about a plan's worth of time (SPMV_PR_PLAN_AFTER steps; default 4): same answer as the
+    it has spent about a plan's worth of time (SPMV_DEBUG=pr_plan_after=N steps; default 4): same answer as the
     oracle whether the switch comes after 0, 2 or 4 steps, or never (converged / ran out of steps first)."""
     import os
     n = 300_000
     rp, ci, va = graph(gpu, n, 8, 33, dangling=(2, 150_000))
     try:
         for after, steps, expect_plan in (("2", 100, True), ("0", 100, True), ("4", 3, False), ("4", 100, True)):
-            os.environ["SPMV_PR_PLAN_AFTER"] = after
+            os.environ["SPMV_DEBUG"] = "pr_plan_after=" + after
             A = upload(gpu, rp, ci, va, n)
             tol = 1e-6 if steps == 100 else 0.0
             r = gpu.pagerank(A, gpu.PageRankConfig(0.85, tol, steps))
@@ -430,7 +430,7 @@ def test_pagerank_switches_to_the_tiled_engine_mid_run(gpu, oracle):
             assert_parity(gpu, oracle, A, rp, ci, va, n, r, tolerance=tol, max_iterations=steps)
             gpu.csr_destroy(A)
     finally:
-        del os.environ["SPMV_PR_PLAN_AFTER"]
+        del os.environ["SPMV_DEBUG"]
 
 
 def test_repeated_calls_on_a_power_law_graph_with_long_rows(gpu, oracle):
@@ -476,7 +476,7 @@ def test_config5_pagerank_full_size_against_the_oracle(gpu, oracle):
     # this graph converges before the loop has spent a plan's worth of time on direct steps, so the first call
     # never builds one; the fixed-k runs below force the tiled engine from step 0
     assert not gpu.csr_has_tiled_plan(A.handle)
-    os.environ["SPMV_PR_PLAN_AFTER"] = "0"
+    os.environ["SPMV_DEBUG"] = "pr_plan_after=0"
 
     rp, ci, va = A.to_host()
     k = 2
@@ -502,7 +502,7 @@ def test_config5_pagerank_full_size_against_the_oracle(gpu, oracle):
         assert info is not None and not info.get("values_folded")
         compare(general.ranks, want)                                  # general plan
     finally:
-        del os.environ["SPMV_PR_PLAN_AFTER"]
+        del os.environ["SPMV_DEBUG"]
         if previous is None:
             del os.environ["SPMV_TILED_FOLD"]
         else:

@@ -430,7 +430,7 @@ def test_both_placing_passes_build_the_same_plan(gpu, monkeypatch):
         cfg = gpu.SpMVConfig(kernel, 256, True)
         seen = {}
         for form in ("staged", "scattered", "staged"):
-            monkeypatch.setenv("SPMV_TILED_PLACE", form)
+            monkeypatch.setenv("SPMV_DEBUG", "place=" + form)
             gpu.csr_invalidate_gpu_cache(A.handle)
             assert gpu.spmv_csr(A.handle, x, y, cfg, A.cols).error_code == 0
             sums = gpu.csr_tiled_checksum(A.handle)
@@ -444,7 +444,7 @@ def test_both_placing_passes_build_the_same_plan(gpu, monkeypatch):
                 assert np.array_equal(bits, seen["bits"]), form
             else:
                 seen = {"sums": sums, "bits": bits}
-        monkeypatch.delenv("SPMV_TILED_PLACE")
+        monkeypatch.delenv("SPMV_DEBUG")
         x.release()
         y.release()
         A.close()
@@ -453,7 +453,7 @@ def test_both_placing_passes_build_the_same_plan(gpu, monkeypatch):
 def test_stable_binning_and_ranking_by_comparison_build_the_same_plan(gpu, oracle, monkeypatch):
     """The builder's ranking pass sends every entry straight to its final place in its strip's bin (stable binning: the
     entries of a batch arrive in (row, column) order) and falls back to ranking by comparison when a bin holds more than
-    255 entries or comes out unordered (rows whose columns are not ascending).  SPMV_TILED_RANK=plain forces the
+    255 entries or comes out unordered (rows whose columns are not ascending).  SPMV_DEBUG=rank=plain forces the
     comparison everywhere.  Same layout either way: equal checksums, bit-equal y — on a uniform matrix, a power-law one
     (long rows: mixed batches), one with few strips and fat bins (> 255 entries per bin: the fallback inside the default
     build), and one whose rows hold their columns in DESCENDING order (the order check must catch it)."""
@@ -480,7 +480,7 @@ def test_stable_binning_and_ranking_by_comparison_build_the_same_plan(gpu, oracl
         cfg = gpu.SpMVConfig(kernel, 256, True)
         seen = {}
         for form in ("stable", "plain", "stable"):
-            monkeypatch.setenv("SPMV_TILED_RANK", form)
+            monkeypatch.setenv("SPMV_DEBUG", "rank=" + form)
             gpu.csr_invalidate_gpu_cache(A.handle)
             assert gpu.spmv_csr(A.handle, x, y, cfg, A.cols).error_code == 0
             sums = gpu.csr_tiled_checksum(A.handle)
@@ -491,7 +491,7 @@ def test_stable_binning_and_ranking_by_comparison_build_the_same_plan(gpu, oracl
                 assert np.array_equal(bits, seen["bits"]), (name, form)
             else:
                 seen = {"sums": sums, "bits": bits}
-        monkeypatch.delenv("SPMV_TILED_RANK")
+        monkeypatch.delenv("SPMV_DEBUG")
         if name == "descending":                # and the result is right, not just the same twice
             rp, ci, va = A.to_host()
             xh = x.copyToHost(A.cols)

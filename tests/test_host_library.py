@@ -309,6 +309,40 @@ def test_tiled_engine_shape_rules(spmv):
         assert tiles < 512 or tiles % 512 == 0 or tiles % 512 > 450                  # whole rounds of resident tiles
 
 
+def test_the_one_debug_variable_overrides_thresholds_and_shape(spmv, monkeypatch):
+    """SPMV_DEBUG="key=value,key,..." (csrc/internal.h) is the library's only tuning / debugging variable and is read at
+    every use: thresholds and shape of the tiled engine follow it from one call to the next; keys that are prefixes of
+    other keys, unknown keys and malformed values are harmless."""
+    small = (5_000, 5_000, 40_000)
+    assert not spmv.tiled_shape(*small)[0]
+    monkeypatch.setenv("SPMV_DEBUG", "min_cols=1,min_nnz=1")
+    assert spmv.tiled_shape(*small)[0]
+    monkeypatch.setenv("SPMV_DEBUG", "rank=plain,min_cols=1,min_nnz=1,strip=4096,tile=1024,nonsense,x=")
+    assert spmv.tiled_shape(*small) == (True, 4096, 1024)
+    monkeypatch.setenv("SPMV_DEBUG", "min_cols=1,min_nnz=1,strip=5000,tile=1000")          # not a power of two / not a multiple of 64: ignored
+    takes, w, r = spmv.tiled_shape(*small)
+    assert takes and w in (4096, 8192, 16384, 32768) and r % 64 == 0
+    monkeypatch.setenv("SPMV_DEBUG", "tiles=7,stripe=3,min_colsx=1,min_nnz=1")             # longer keys do not match shorter ones
+    assert not spmv.tiled_shape(*small)[0]
+    monkeypatch.setenv("SPMV_DEBUG", "min_nnz=999999999,min_cols=1")
+    assert not spmv.tiled_shape(10_000_000, 10_000_000, 160_000_000)[0]
+    monkeypatch.delenv("SPMV_DEBUG")
+    assert spmv.tiled_shape(10_000_000, 10_000_000, 160_000_000)[0] and not spmv.tiled_shape(*small)[0]
+
+
+def test_the_library_reads_few_environment_variables(spmv):
+    """at most ten SPMV_* variables in the product sources, every one of them listed in INTEGRATION.md."""
+    import glob
+    import re
+    names = set()
+    for path in glob.glob(os.path.join(ROOT, "gpu-spmv_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "**", "*.h"), recursive=True):
+        names.update(re.findall(r'getenv\("(SPMV_[A-Z0-9_]+)"\)', open(path, errors="replace").read()))
+    assert 0 < len(names) <= 10, sorted(names)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in names:
+        assert name in doc, name
+
+
 def test_shard_engine_rejects_bad_arguments_without_touching_a_gpu(spmv):
     """spmv_c_pr_shard_create validates before any device call: null matrix / mask, negative offsets and a
     node count wider than the matrix header all give NULL (include/spmv_c.h)."""

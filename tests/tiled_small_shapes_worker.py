@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_tiled_small_shapes.py: run with SPMV_TILED_MIN_COLS / SPMV_TILED_MIN_NNZ set so
+"""Worker of tests/test_gpu_tiled_small_shapes.py: run with SPMV_DEBUG=min_cols=1,min_nnz=1 set so
 that SMALL matrices go through the LDS-tiled engine, and compare every case with the CPU oracle.
 (The thresholds are read once per process, hence the separate process.)"""
 import importlib
@@ -128,8 +128,8 @@ def run_length_patterns():
     1100 strips = 69 runs per wavefront) — against the oracle, through VECTOR_CSR and MERGE_PATH with use_texture."""
     import scipy.sparse as sp
     strips, tiles = 1100, 2
-    w, r = 4096, 1024                                  # forced by the test's environment (SPMV_TILED_STRIP / SPMV_TILED_TILE)
-    assert os.environ.get("SPMV_TILED_STRIP") == "4096" and os.environ.get("SPMV_TILED_TILE") == "1024"
+    w, r = 4096, 1024                                  # forced by the test's environment (SPMV_DEBUG=strip=4096,tile=1024)
+    assert "strip=4096" in os.environ.get("SPMV_DEBUG", "") and "tile=1024" in os.environ.get("SPMV_DEBUG", "")
     rows, cols = tiles * r, strips * w
     base = [0, 0, 3, 4, 5, 252, 256, 260, 0, 1, 511, 512, 513, 64, 64, 64, 64, 7] + [0] * 53 + [1000, 2, 0, 0, 1500, 8, 248, 12]
     rng = np.random.default_rng(99)

@@ -16,8 +16,9 @@ python3 - "$out" <<'PY'
 import collections, re, statistics, sys
 acc = collections.defaultdict(list)
 for line in open(sys.argv[1]):
-    m = re.match(r"(cfg\d+) round\d+ \[(.*?)\] (.*?)\s+kernel=(\d+).*avg=\s*([\d.]+)us", line)
-    if m: acc[(m.group(1), m.group(2), m.group(3).strip() + " k" + m.group(4))].append(float(m.group(5)))
-for (cfg, env, name), v in sorted(acc.items()):
-    print(f"{cfg} [{env or 'defaults'}] {name:22s} median {statistics.median(v):8.1f} us   all {v}")
+    m = re.match(r"(cfg\d+) round\d+ \[(.*?)\] (.*?)\s+kernel=(\d+).*avg=\s*([\d.]+)us min=\s*([\d.]+)us", line)
+    if m: acc[(m.group(1), m.group(2), m.group(3).strip() + " k" + m.group(4))].append((float(m.group(5)), float(m.group(6))))
+for (cfg, env, name), v in sorted(acc.items(), key=lambda kv: (kv[0][2], int(kv[0][0][3:]))):
+    avgs, mins = [a for a, _ in v], [b for _, b in v]
+    print(f"{cfg} [{env or 'defaults'}] {name:22s} median avg {statistics.median(avgs):8.1f} us  best min {min(mins):8.1f} us   avgs {avgs}")
 PY

@@ -3,9 +3,9 @@
 out=gpurun_out/long_sweep.txt
 : > $out
 run() { echo "== $*" >> $out; env "$@" python tools/quick_bench.py c4only c5pl 2>&1 | grep "kernel=12\|plan" >> $out; }
-run SPMV_TILED_LONG_FACTOR=2
-run SPMV_TILED_LONG_FACTOR=4
-run SPMV_TILED_LONG_FACTOR=8 SPMV_TILED_LONG_CAP=4096
-run SPMV_TILED_LONG_FACTOR=16 SPMV_TILED_LONG_CAP=8192
-run SPMV_TILED_LONG_FACTOR=1000 SPMV_TILED_LONG_CAP=100000
+run SPMV_DEBUG=long_factor=2
+run SPMV_DEBUG=long_factor=4
+run SPMV_DEBUG=long_factor=8,long_cap=4096
+run SPMV_DEBUG=long_factor=16,long_cap=8192
+run SPMV_DEBUG=long_factor=1000,long_cap=100000
 cat $out

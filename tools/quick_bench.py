@@ -75,7 +75,7 @@ def main():
         A = wl.power_law_csr_device(42, 10_000_000, 10_000_000)
         print("c5pl nnz", A.nnz, flush=True); report("10M power-law", A, kernels=(12, 2))
         print("plan", spmv.csr_tiled_info(A.handle), flush=True); A.close()
-    if "onestrip" in which:   # run with SPMV_TILED_MIN_COLS=1: ONE strip, so every tile's entries are one contiguous run
+    if "onestrip" in which:   # run with SPMV_DEBUG=min_cols=1: ONE strip, so every tile's entries are one contiguous run
         A = wl.uniform_csr_device(42, 10_000_000, 32_768, 16); report("10M x 32K cols (1 strip)", A, kernels=(11,))
         print("plan", spmv.csr_tiled_info(A.handle), flush=True); A.close()
     if "c5only" in which:

@@ -35,20 +35,16 @@ struct TiledPlan {
     uint8_t*  a_drow = nullptr;     // [nnz] row - (row of the cell's previous slot), 0..254; 255 = advance 255 rows, no entry
     float*    prod = nullptr;       // [nnz] phase-1 output / phase-2 input, same order
     int*      cells_t = nullptr;    // [2 * num_tiles * num_strips]: (begin, length) pairs, tile-major
+    // phase 2's work, laid out at build time (tiled.hip, pass_layout_kernel): the slots of wavefront w of tile t's workgroup
+    // are the passes [pass_first[16 t + w], pass_first[16 t + w + 1]), one 32-byte descriptor each
+    int*      pass_first = nullptr; // [16 * num_tiles + 1]
+    void*     pass_desc = nullptr;  // [num_passes] PassDesc
+    long long num_passes = 0;
 
     // phase-1 work items: (strip, begin, end), at most kItemEntries slots each
     int* items = nullptr;           // [3 * num_items]
     int  num_items = 0;
     int* strip_first_item = nullptr; // HOST [num_strips + 1]: the items are sorted by strip
-    // EXPERIMENT (SPMV_TILED_PARTS=n): the tiles cut into n row parts; behind the strip-major items a second,
-    // part-major list (per part: every strip's slots of that part's tiles), so that phase 2 of part p can run
-    // beside phase 1 of part p + 1 on a side stream
-    int num_parts = 1;
-    std::vector<int> part_first_tile;   // HOST [parts + 1]
-    std::vector<int> part_first_item;   // HOST [parts + 1] (absolute indices into items)
-    mutable hipStream_t side_stream = nullptr;
-    mutable std::vector<hipEvent_t> part_events;   // [parts]: [p] = phase 1 of part p enqueued; [parts - 1] = join
-
     // rows longer than long_row: summed by one wavefront per 512-entry chunk from the CSR arrays
     int*   long_rows = nullptr;     // [num_long] ascending
     int    num_long = 0;

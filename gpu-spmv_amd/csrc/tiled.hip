@@ -86,27 +86,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
-// EXPERIMENT: non-temporal hints on the once-read / once-written streams (SPMV_NT_MASK: 1 = phase-1 loads,
-// 2 = phase-1 product stores, 4 = phase-2 loads)
-#ifndef SPMV_NT_MASK
-#define SPMV_NT_MASK 0
-#endif
-template <int BIT, typename T>
-__device__ __forceinline__ T stream_load(const T* p) {
-    if constexpr ((SPMV_NT_MASK & BIT) != 0) return __builtin_nontemporal_load(p);
-    else return *p;
-}
-#ifndef SPMV_STORE_ASM
-#define SPMV_STORE_ASM 0        // 1: sc1, 2: sc1 nt, 3: sc0 sc1 (16-byte product stores by inline asm)
-#endif
-template <int BIT, typename T>
-__device__ __forceinline__ void stream_store(T* p, T v) {
-    if constexpr (SPMV_STORE_ASM == 1 && sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
-    else if constexpr (SPMV_STORE_ASM == 2 && sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p), "v"(v) : "memory");
-    else if constexpr (SPMV_STORE_ASM == 3 && sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
-    else if constexpr ((SPMV_NT_MASK & BIT) != 0) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
+// The products are written once and read once, by other CUs, a whole kernel later: stored NON-TEMPORAL they do not linger
+// as dirty lines in the Infinity Cache, whose write-back would otherwise compete with phase 2's reads (phase 1 takes
+// ~13 us longer on C5, phase 2 ~29 us less: 518 -> 509 us per SpMV same box, 512 -> 489 on another;
+// profiles/r04_store_flavours.txt — sc1 / sc0 sc1 write-through stores and nt LOADS on either phase lose).
+template <typename T>
+__device__ __forceinline__ void store_product(T* p, T v) { __builtin_nontemporal_store(v, p); }
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each XCD has its
 // own L2).  Both phases hand every XCD a CONTIGUOUS range of the work list, walked in order:
@@ -1193,36 +1178,29 @@ void tiled_expand_kernel(const int* __restrict__ items, int first_item, int num_
                 f32x4 lo, hi;
                 lo[0] = xs[c[0]]; lo[1] = xs[c[1]]; lo[2] = xs[c[2]]; lo[3] = xs[c[3]];
                 hi[0] = xs[c[4]]; hi[1] = xs[c[5]]; hi[2] = xs[c[6]]; hi[3] = xs[c[7]];
-                *reinterpret_cast<f32x4*>(prod + q) = lo;
-                *reinterpret_cast<f32x4*>(prod + q + 4) = hi;
+                store_product(reinterpret_cast<f32x4*>(prod + q), lo);
+                store_product(reinterpret_cast<f32x4*>(prod + q + 4), hi);
             } else {
                 for (int k = max(q, begin); k < min(q + 8, end); ++k) prod[k] = xs[a_lcol[k]];
             }
         }
         return;
     }
-    // four entries per lane per step, groups aligned to 4 entries (16-byte loads and stores)
+    // four entries per lane per step, groups aligned to 4 entries (16-byte loads and stores).  (Round 4 tried four groups
+    // per lane with all loads issued up front, and the same for the strip staging above: 311.8 against 306.9 us on C5,
+    // profiles/r04_kernel_ab_descriptors.txt — phase 1 runs at the rate its 10 bytes per slot allow, not at a latency bound.)
     for (int q = (begin & ~3) + threadIdx.x * 4; q < end; q += kExpandBlock * 4) {
         if (q >= begin && q + 3 < end) {
-            const u16x4 c = stream_load<1>(reinterpret_cast<const u16x4*>(a_lcol + q));
+            const u16x4 c = *reinterpret_cast<const u16x4*>(a_lcol + q);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a_val + q);
             f32x4 p;
-            if (FOLD) {
-                p[0] = xs[c[0]];
-                p[1] = xs[c[1]];
-                p[2] = xs[c[2]];
-                p[3] = xs[c[3]];
-            } else {
-                const f32x4 v = stream_load<1>(reinterpret_cast<const f32x4*>(a_val + q));
-                p[0] = v[0] * xs[c[0]];
-                p[1] = v[1] * xs[c[1]];
-                p[2] = v[2] * xs[c[2]];
-                p[3] = v[3] * xs[c[3]];
-            }
-            stream_store<2>(reinterpret_cast<f32x4*>(prod + q), p);
+            p[0] = v[0] * xs[c[0]];
+            p[1] = v[1] * xs[c[1]];
+            p[2] = v[2] * xs[c[2]];
+            p[3] = v[3] * xs[c[3]];
+            store_product(reinterpret_cast<f32x4*>(prod + q), p);
         } else {
-            for (int k = max(q, begin); k < min(q + 4, end); ++k) {
-                prod[k] = FOLD ? xs[a_lcol[k]] : a_val[k] * xs[a_lcol[k]];
-            }
+            for (int k = max(q, begin); k < min(q + 4, end); ++k) prod[k] = a_val[k] * xs[a_lcol[k]];
         }
     }
 }
@@ -1249,36 +1227,144 @@ struct LongSeeds {
     const float* chunk_sum;   // [num_chunks] written by phase 1 of this SpMV
 };
 
-#ifndef SPMV_STREAM_DEPTH
-#define SPMV_STREAM_DEPTH 2
-#endif
-#ifndef SPMV_STREAM_SEGS
-#define SPMV_STREAM_SEGS 3      // segments per pass: 2 / 3 / 4 measured 492 / 482 / 483 us on C5, 47.9 / 48.7 / 51.9 on C2, 41.6 / 42.4 / 44.2 on C4
-#endif
+// ---- phase 2 as a list of PASSES laid out when the plan is built (round 4) ----
+// A tile's slots are one run per strip (cell table); a wavefront of the tile's workgroup owns a contiguous share of the
+// strips and walks its runs as ONE stream of slots, 256 per PASS whatever the run boundaries: a pass is up to kPassSegs
+// SEGMENTS (the end of one run, whole short runs, the start of the next), 4 slots per lane.  Round 3 derived the segments
+// inside the kernel, from the (begin, length) records of the runs — ~100 scalar instructions and ~18 branches per pass,
+// and with 8 wavefronts per SIMD sharing one scalar issue slot every 4 cycles that was the kernel's bound: a phase 2 that
+// only LOADS (no row rebuild, no LDS adds) took 192 us of the full kernel's 200, whatever the access pattern, the loads in
+// flight or the source array (profiles/r04_phase2_bound.txt).  Everything the scalar code computed is a function of the
+// plan alone, so it is computed ONCE, by pass_layout_kernel below, into one 32-byte descriptor per pass:
+//     base[k]  slot index lane 0 WOULD read if it belonged to segment k (a lane reads base + 4 * lane)
+//     adj[k]   row of the slot in front of segment k's first slot (0 at a run's start) minus the sum of the delta bytes
+//              of all lanes in front of the segment: row of a slot = adj[segment] + (wave-wide exclusive prefix of the lanes'
+//              delta sums) + the in-lane prefix — no carry from pass to pass, nothing read back from the scan
+//     geom     first lane of segments 1 and 2, lanes in use
+// The hot loop is then: 8 v_readlane per pass, two loads, one wave scan, four ds_add_f64 — and passes are independent of
+// each other, so the next ones' loads are always in flight.  Same slots, same rows, same fp64 adds as the round-3 form:
+// bit-identical results (tests/tiled_small_shapes_worker.py: ~150 awkward shapes and the hand-picked run-length patterns —
+// every boundary case of a pass — against the oracle).
+constexpr int kPassSegs = 3;            // segments per pass: 2 / 3 / 4 measured 492 / 482 / 483 us on C5 in round 3
+constexpr int kPassSlots = 256;         // slots per pass: four per lane
+constexpr int kPassDepth = 3;           // passes in flight per wavefront (2 / 3 / 4: 158.7 / 157.0 / 156.9 us on C5)
+constexpr int kReduceThreads = 1024;
+constexpr int kReduceWaves = kReduceThreads / 64;
+
+struct PassDesc {                       // 32 bytes = two 16-byte loads
+    int base[kPassSegs];
+    int adj[kPassSegs];
+    unsigned int geom;                  // start[1] | start[2] << 8 | lanes in use << 16
+    unsigned int reserved;
+};
+static_assert(sizeof(PassDesc) == 32, "a lane loads its pass descriptor as two 16-byte words");
+
+// the strips (= runs of a tile) wavefront `wave` of a tile's workgroup owns
+__device__ __forceinline__ void wave_runs(int num_strips, int wave, int* lo, int* hi) {
+    const int per_wave = (num_strips + kReduceWaves - 1) / kReduceWaves;
+    *lo = min(num_strips, wave * per_wave);
+    *hi = min(num_strips, *lo + per_wave);
+}
+
+// Lays out the passes of every (tile, wavefront): FILL = false counts them (-> pass_count[tile * 16 + wave]), FILL = true
+// writes their descriptors at pass_first[tile * 16 + wave].  One 1024-thread workgroup per tile, wavefront w does the share
+// of wavefront w of the phase-2 workgroup.  The (begin, length) records of a wavefront's runs come 64 at a time (lane l holds
+// run window_first + l, read back with v_readlane); a pass never straddles two such windows.
+template <bool FILL>
+__global__ __launch_bounds__(kReduceThreads)
+void pass_layout_kernel(int num_tiles, int num_strips, const int2* __restrict__ cells_t,
+                        const unsigned char* __restrict__ a_drow,
+                        int* __restrict__ pass_count, const int* __restrict__ pass_first, PassDesc* __restrict__ desc) {
+    const int tile_index = blockIdx.x;
+    if (tile_index >= num_tiles) return;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    int run_lo, run_hi;
+    wave_runs(num_strips, wave, &run_lo, &run_hi);
+    const int2* mine = cells_t + static_cast<long long>(tile_index) * num_strips;
+    int passes = 0;
+    long long out = FILL ? pass_first[tile_index * kReduceWaves + wave] : 0;
+    for (int window_first = run_lo; window_first < run_hi; window_first += 64) {
+        const int2 window = window_first + lane < run_hi ? mine[window_first + lane] : make_int2(0, 0);
+        const int window_runs = min(64, run_hi - window_first);
+        int next_run = 0, cur_begin = 0, cur_len = 0, off = 0;     // the stream cursor (wave-uniform)
+        int row_carry = 0;                                         // the row the open run has reached
+        for (;;) {
+            int base[kPassSegs], start[kPassSegs];
+            int filled = 0, last = 0;
+            bool fresh0 = true;
+#pragma unroll
+            for (int k = 0; k < kPassSegs; ++k) {
+                while (off >= cur_len && next_run < window_runs) {       // the next run that holds slots (banded matrices: most are empty)
+                    cur_begin = __builtin_amdgcn_readlane(window.x, next_run);
+                    cur_len = __builtin_amdgcn_readlane(window.y, next_run);
+                    off = 0;
+                    ++next_run;
+                }
+                const int take = max(min(cur_len - off, kPassSlots - filled), 0);
+                if (k == 0) fresh0 = off == 0;
+                base[k] = cur_begin + off - filled;
+                start[k] = filled >> 2;
+                last = take > 0 ? k : last;
+                filled += take;
+                off += take;
+            }
+            if (filled == 0) break;
+            ++passes;
+            if (!FILL) continue;
+            const bool open_end = off < cur_len;
+            const int groups = filled >> 2;
+            // the delta bytes of the pass: what phase 2 will read, lane by lane
+            const int at = min(lane, groups - 1);
+            int mine_base = base[0];
+#pragma unroll
+            for (int k = 1; k < kPassSegs; ++k) mine_base = at >= start[k] ? base[k] : mine_base;
+            const unsigned int word = lane < groups ? *reinterpret_cast<const unsigned int*>(a_drow + mine_base + 4 * at) : 0u;
+            const int sum = static_cast<int>((word & 0xFF) + ((word >> 8) & 0xFF) + ((word >> 16) & 0xFF) + (word >> 24));
+            const int incl = wave_inclusive_scan(sum);
+            // row in front of each segment, and the delta sums in front of it
+            int adj[kPassSegs];
+            int origin = fresh0 ? 0 : row_carry;
+            adj[0] = origin;
+#pragma unroll
+            for (int k = 1; k < kPassSegs; ++k) {
+                const int before = start[k] > 0 ? __builtin_amdgcn_readlane(incl, max(start[k] - 1, 0)) : 0;
+                adj[k] = -before;                          // a segment behind the first starts a run: its rows count from 0
+                origin = k <= last ? adj[k] : origin;
+            }
+            row_carry = open_end ? origin + __builtin_amdgcn_readlane(incl, groups - 1) : 0;
+            if (lane == 0) {
+                PassDesc d;
+#pragma unroll
+                for (int k = 0; k < kPassSegs; ++k) {
+                    d.base[k] = base[k];
+                    d.adj[k] = adj[k];
+                }
+                d.geom = static_cast<unsigned int>(start[1]) | static_cast<unsigned int>(start[2]) << 8 | static_cast<unsigned int>(groups) << 16;
+                d.reserved = 0;
+                desc[out] = d;
+            }
+            ++out;
+        }
+    }
+    if (!FILL && lane == 0) pass_count[tile_index * kReduceWaves + wave] = passes;
+}
+
 // Fills the LDS tile with the sums of this tile's rows; the long rows' sums come from their chunk sums.  The tile
 // accumulates in DOUBLE: every fp32 product is added exactly as often as fp64 allows (products of one row rarely span
 // more than 29 binades), so the row sums do not depend on the order in which the wavefronts' adds meet, and they are
 // rounded to fp32 once, on the way out.
-// The runs a wavefront owns (one per strip, a contiguous share of the strips) are walked as ONE stream of slots, 256 per
-// pass whatever the run boundaries (round 3; the run-by-run walk it replaced spent a third of its passes on run tails —
-// profiles/r03_phase2_probes.txt — and was retired in round 4): a pass is up to kSegs SEGMENTS (the end of one run, whole
-// short runs, the start of the next), every lane picks its segment's base by comparing its lane number with the
-// segments' first lanes, the row of a slot is its wave-wide prefix sum of the row deltas minus the prefix sum at the end
-// of the previous segment (read with v_readlane: the boundaries are wave-uniform), and the run that continues into the
-// next pass carries its row over in a scalar.  Run geometry lives in scalar registers, addresses are a scalar base + one
-// shared lane offset, and passes are software-pipelined (the next passes' loads are in flight while this one adds).
-template <int kReduceBlock, int kSegs>
-__device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int tile_index, int num_strips, int num_rows,
-                                                       const int2* __restrict__ cells_t,
-                                                       const float* __restrict__ prod,
-                                                       const unsigned char* __restrict__ a_drow,
-                                                       const LongSeeds seeds) {
+__device__ __forceinline__ void tile_accumulate(double* tile, int R, int tile_index,
+                                                const int* __restrict__ pass_first, const PassDesc* __restrict__ desc,
+                                                const float* __restrict__ prod,
+                                                const unsigned char* __restrict__ a_drow,
+                                                const LongSeeds seeds) {
     __shared__ double spare[64];           // where a lane's slots without an entry "add" (never read)
     const long long first = static_cast<long long>(tile_index) * R;
-    for (int i = threadIdx.x; i < R; i += kReduceBlock) tile[i] = 0.0;
+    for (int i = threadIdx.x; i < R; i += kReduceThreads) tile[i] = 0.0;
     if (seeds.tile_first) {
         __syncthreads();
-        for (int k = seeds.tile_first[tile_index] + threadIdx.x; k < seeds.tile_first[tile_index + 1]; k += kReduceBlock) {
+        for (int k = seeds.tile_first[tile_index] + threadIdx.x; k < seeds.tile_first[tile_index + 1]; k += kReduceThreads) {
             double total = 0.0;                         // a long row's chunk sums, in chunk order
             for (int c = seeds.first_chunk[k]; c < seeds.first_chunk[k + 1]; ++c) total += static_cast<double>(seeds.chunk_sum[c]);
             tile[seeds.rows[k] - first] = total;
@@ -1286,102 +1372,49 @@ __device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int 
     }
     __syncthreads();
 
-    constexpr int kSpan = 256;             // slots per pass: four per lane
-    constexpr int kDepth = SPMV_STREAM_DEPTH;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    constexpr int kWaves = kReduceBlock / 64;
-    const int per_wave = (num_strips + kWaves - 1) / kWaves;
-    const int run_lo = min(num_strips, wave * per_wave), run_hi = min(num_strips, run_lo + per_wave);
-    const int2* mine = cells_t + static_cast<long long>(tile_index) * num_strips;
+    const int pass_lo = pass_first[tile_index * kReduceWaves + wave], pass_hi = pass_first[tile_index * kReduceWaves + wave + 1];
 
     struct Pass {
-        bool valid, fresh0, open_end;      // fresh0: segment 0 starts a run; open_end: the last segment's run goes on in the next pass
-        int groups;                        // 4-slot groups (= lanes) in use
-        int base[kSegs];                   // slot index lane 0 WOULD read if it belonged to the segment: a lane reads base + 4 * lane
-        int start[kSegs];                  // first lane of the segment
-        int last;                          // the last segment that holds slots
+        int lane_adj;                      // adj of the lane's segment (selected when the pass is opened: a select over struct
+        int groups;                        //  members kept for later turns into an indexed load from scratch memory)
         f32x4 p;
         unsigned int d;
     };
-    int row_carry = 0;                     // wave-uniform: the row the open run has reached (0 at a run's start)
-#if defined(SPMV_PROBE_P2)
-    float probe_acc = 0.f;
-    int probe_pass = 0;
-    // (all slots of the plan: the end of the last cell, rounded down so that a lane's 16-byte load stays inside)
-    const int probe_tiles = (num_rows + R - 1) / R;
-    const int2 probe_last = cells_t[static_cast<long long>(probe_tiles) * num_strips - 1];
-    const long long probe_slots = max(256, (probe_last.x + probe_last.y) / 256 * 256);
-#endif
+    // descriptors 64 at a time: lane l holds pass window_first + l
+    for (int window_first = pass_lo; window_first < pass_hi; window_first += 64) {
+        const uint4* mine = reinterpret_cast<const uint4*>(desc + window_first + min(lane, pass_hi - window_first - 1));
+        uint4 lo = mine[0], hi = mine[1];
+        // (waited for HERE, once: read for the first time inside the loop below, the compiler would wait vmcnt(0) — the
+        // passes' own loads included — at every pass it opens)
+        asm volatile("; pass descriptors settled" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(lo.w), "+v"(hi.x), "+v"(hi.y), "+v"(hi.z));
+        const int window_passes = min(64, pass_hi - window_first);
 
-    // The (begin, length) records of the wavefront's runs come 64 at a time (lane l holds run window_first + l); inside
-    // a window everything below is scalar arithmetic on v_readlane'd values — no load but the two of a pass, so the
-    // compiler's s_waitcnt bookkeeping stays exact.  A pass never straddles two windows (the stream is cut there).
-    for (int window_first = run_lo; window_first < run_hi; window_first += 64) {
-        int2 window = window_first + lane < run_hi ? mine[window_first + lane] : make_int2(0, 0);
-        // the records are waited for HERE, once: read for the first time inside the loop below, the compiler would wait
-        // for them (vmcnt(0): everything in flight, the passes' own loads included) at every run it opens
-        asm volatile("; window records settled" : "+v"(window.x), "+v"(window.y));
-        const int window_runs = min(64, run_hi - window_first);
-        int next_run = 0, cur_begin = 0, cur_len = 0, off = 0;     // the stream cursor (wave-uniform)
-        row_carry = 0;
-
-        auto build = [&](Pass& ps) {
-            int filled = 0;
-            ps.fresh0 = true;
-            ps.last = 0;
-#pragma unroll
-            for (int k = 0; k < kSegs; ++k) {
-                while (off >= cur_len && next_run < window_runs) {       // step to the next run that holds slots (banded matrices: most are empty)
-                    const int idx = __builtin_amdgcn_readfirstlane(next_run);
-                    cur_begin = __builtin_amdgcn_readlane(window.x, idx);
-                    cur_len = __builtin_amdgcn_readlane(window.y, idx);
-                    off = 0;
-                    ++next_run;
-                }
-                const int take = max(min(cur_len - off, kSpan - filled), 0);
-                if (k == 0) ps.fresh0 = off == 0;
-                ps.base[k] = cur_begin + off - filled;
-                ps.start[k] = filled >> 2;
-                ps.last = take > 0 ? k : ps.last;
-                filled += take;
-                off += take;
-            }
-            ps.open_end = off < cur_len;
-            ps.groups = filled >> 2;
-            ps.valid = filled > 0;
+        auto open = [&](Pass& ps, int k) {            // pass k of the window (k < window_passes): geometry + its two loads
+            const int idx = __builtin_amdgcn_readfirstlane(k);
+            const int base0 = __builtin_amdgcn_readlane(static_cast<int>(lo.x), idx);
+            const int base1 = __builtin_amdgcn_readlane(static_cast<int>(lo.y), idx);
+            const int base2 = __builtin_amdgcn_readlane(static_cast<int>(lo.z), idx);
+            const int adj0 = __builtin_amdgcn_readlane(static_cast<int>(lo.w), idx);
+            const int adj1 = __builtin_amdgcn_readlane(static_cast<int>(hi.x), idx);
+            const int adj2 = __builtin_amdgcn_readlane(static_cast<int>(hi.y), idx);
+            const unsigned int geom = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(hi.z), idx));
+            const int start1 = static_cast<int>(geom & 0xFF), start2 = static_cast<int>((geom >> 8) & 0xFF);
+            ps.groups = static_cast<int>(geom >> 16);
+            // lanes past the pass's end re-read its last group (same cache line) and are masked in add()
+            const int at = min(lane, ps.groups - 1);
+            int base = base0, adj = adj0;
+            base = at >= start1 ? base1 : base;
+            adj = at >= start1 ? adj1 : adj;
+            base = at >= start2 ? base2 : base;
+            adj = at >= start2 ? adj2 : adj;
+            ps.lane_adj = adj;
+            const unsigned int slot = static_cast<unsigned int>(base + 4 * at);
+            ps.p = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(prod) + (static_cast<size_t>(slot) << 2));
+            ps.d = *reinterpret_cast<const unsigned int*>(a_drow + slot);
         };
-        auto issue_loads = [&](Pass& ps) {
-            // lanes past the pass's end re-read its last group (same cache line) and are masked below; a pass behind the
-            // stream's end (nothing in it) still issues its two loads — of slot 0 —, so that every pass costs the
-            // counters the same and the waits in front of process() stay "all but the newer pass's loads"
-            const int at = max(min(lane, ps.groups - 1), 0);
-            int base = ps.valid ? ps.base[0] : 0;
-#pragma unroll
-            for (int k = 1; k < kSegs; ++k) base = at >= ps.start[k] && ps.valid ? ps.base[k] : base;
-            unsigned int slot = static_cast<unsigned int>(base + 4 * at);
-#if defined(SPMV_PROBE_P2) && (SPMV_PROBE_P2 == 14 || SPMV_PROBE_P2 == 15)      // timing probes (with the loads-only body): every wavefront reads ONE contiguous range
-            slot = static_cast<unsigned int>((((static_cast<long long>(tile_index) * kWaves + wave) * 48 + (probe_pass++ % 48)) * 256 + 4 * lane) % probe_slots);
-#endif
-            ps.p = stream_load<4>(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(prod) + (static_cast<size_t>(slot) << 2)));
-#if defined(SPMV_PROBE_P2) && (SPMV_PROBE_P2 == 13 || SPMV_PROBE_P2 == 15 || SPMV_PROBE_P2 == 17)    // ... without the 4-byte delta load
-            ps.d = slot;
-#else
-            ps.d = stream_load<4>(reinterpret_cast<const unsigned int*>(a_drow + slot));
-#endif
-        };
-        auto process = [&](const Pass& ps) {
-#if defined(SPMV_PROBE_P2) && (SPMV_PROBE_P2 == 10 || SPMV_PROBE_P2 >= 13)       // timing probe: loads only (no decode, no LDS adds); results wrong
-            probe_acc += ps.p[0] + ps.p[1] + ps.p[2] + ps.p[3] + __uint_as_float(ps.d);
-            return;
-#elif defined(SPMV_PROBE_P2) && SPMV_PROBE_P2 == 12     // timing probe: loads + LDS adds, rows without any decode; results wrong
-            {
-                const int fake = (lane * 4 + static_cast<int>(ps.d & 0xFF)) % (R - 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(&tile[fake + e], static_cast<double>(ps.p[e]));
-                return;
-            }
-#endif
+        auto add = [&](const Pass& ps) {
             const unsigned int word = lane < ps.groups ? ps.d : 0xFFFFFFFFu;
             int delta[4], upto[4], sum = 0;
 #pragma unroll
@@ -1391,66 +1424,68 @@ __device__ __forceinline__ void tile_accumulate_stream(double* tile, int R, int 
                 upto[e] = sum;
             }
             const int incl = wave_inclusive_scan(sum);
-            // a segment behind the first starts a run: its rows count from the prefix sum at the end of the segment before it
-            int origin = ps.fresh0 ? 0 : row_carry;
-            int lane_origin = origin;
-#pragma unroll
-            for (int k = 1; k < kSegs; ++k) {
-                const int before = __builtin_amdgcn_readlane(incl, max(ps.start[k] - 1, 0));
-                const int mine_k = ps.start[k] > 0 ? -before : 0;
-                lane_origin = lane >= ps.start[k] ? mine_k : lane_origin;
-                origin = k <= ps.last ? mine_k : origin;
-            }
-            const int lane_base = lane_origin + incl - sum;
-            row_carry = ps.open_end ? origin + __builtin_amdgcn_readlane(incl, max(ps.groups - 1, 0)) : 0;
-#if defined(SPMV_PROBE_P2) && SPMV_PROBE_P2 == 11       // timing probe: loads + decode, no LDS adds; results wrong
-#pragma unroll
-            for (int e = 0; e < 4; ++e) probe_acc += ps.p[e] * static_cast<float>(delta[e] != kSkip ? lane_base + upto[e] : lane);
-#else
+            const int lane_base = ps.lane_adj + incl - sum;
+            // One LDS atomic per slot: ds_add_f64 (no return value, no retry loop, equal rows in one instruction are the
+            // hardware's business; gfx950 runs it at 3.5 lanes/clk/CU on random rows, the fp32 form at 0.38 —
+            // tools/lds_bench.hip).  Skip markers aim at a per-lane spare word, so nothing here needs an execution mask.
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 double* target = delta[e] != kSkip ? &tile[lane_base + upto[e]] : &spare[lane];
                 atomicAdd(target, static_cast<double>(ps.p[e]));
             }
-#endif
         };
 
-        // kDepth passes in flight, pass i of the stream in slot i mod kDepth; every slot always holds issued loads
-        Pass ps[kDepth];
+        // kPassDepth passes in flight, pass i of the window in slot i mod kPassDepth.  The steady-state loop holds nothing
+        // but the pipeline (every add is followed by an open: no branch around a load, so the compiler's s_waitcnt in front
+        // of an add counts exactly the newer passes' loads); what is left at the end is drained by the two short tails.
+        Pass ps[kPassDepth];
 #pragma unroll
-        for (int u = 0; u < kDepth; ++u) {
-            build(ps[u]);
-            issue_loads(ps[u]);
+        for (int u = 0; u < kPassDepth; ++u) {
+            // (unconditional — a window shorter than the pipeline re-opens its last pass and never adds it —: with branches
+            // here the loads in flight differ from path to path and the first wait of the loop below becomes vmcnt(0))
+            open(ps[u], min(u, window_passes - 1));
+            __builtin_amdgcn_sched_barrier(0);
         }
-        for (bool more = true; more;) {
+        int k = 0;
+        for (; k + 2 * kPassDepth <= window_passes; k += kPassDepth) {
 #pragma unroll
-            for (int u = 0; u < kDepth; ++u) {
-                if (!ps[u].valid) { more = false; break; }
-                process(ps[u]);
-                build(ps[u]);
-                issue_loads(ps[u]);
+            for (int u = 0; u < kPassDepth; ++u) {
+                // (scheduling barriers: left alone, the compiler gathers the three adds behind ONE s_waitcnt vmcnt(0) and issues
+                // all six loads at the end of the iteration — nothing in flight while a pass is added)
+                add(ps[u]);
+                __builtin_amdgcn_sched_barrier(0);
+                open(ps[u], k + u + kPassDepth);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+#pragma unroll
+        for (int u = 0; u < kPassDepth; ++u) {
+            if (k + u < window_passes) {
+                add(ps[u]);
+                if (k + u + kPassDepth < window_passes) open(ps[u], k + u + kPassDepth);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kPassDepth; ++u) {
+            if (k + kPassDepth + u < window_passes) add(ps[u]);
+        }
     }
-#if defined(SPMV_PROBE_P2)
-    tile[threadIdx.x] += static_cast<double>(probe_acc);
-#endif
     __syncthreads();
 }
 
 // The tile (R doubles, R = plan.tile_rows: any multiple of 64) lives in dynamic LDS.
 template <int kReduceBlock>
 __global__ __launch_bounds__(kReduceBlock, kReduceBlock / 128)     // two tiles per CU: 8 wavefronts per SIMD
-void tiled_reduce_kernel(int R, int first_tile, int num_tiles, const int2* __restrict__ cells_t, int num_strips,
+void tiled_reduce_kernel(int R, int num_tiles, const int* __restrict__ pass_first, const PassDesc* __restrict__ pass_desc,
                          const float* __restrict__ prod,
                          const unsigned char* __restrict__ a_drow,
                          const LongSeeds seeds,
                          int num_rows, float* __restrict__ y) {
+    static_assert(kReduceBlock == kReduceThreads, "the pass layout is made for this workgroup size");
     extern __shared__ double tile[];
-    const int window = xcd_contiguous(blockIdx.x, num_tiles);
-    if (window < 0) return;
-    const int tile_index = first_tile + window;
-    tile_accumulate_stream<kReduceBlock, SPMV_STREAM_SEGS>(tile, R, tile_index, num_strips, num_rows, cells_t, prod, a_drow, seeds);
+    const int tile_index = xcd_contiguous(blockIdx.x, num_tiles);
+    if (tile_index < 0) return;
+    tile_accumulate(tile, R, tile_index, pass_first, pass_desc, prod, a_drow, seeds);
     const long long first = static_cast<long long>(tile_index) * R;
     for (int i = threadIdx.x; i < R && first + i < num_rows; i += kReduceBlock) y[first + i] = static_cast<float>(tile[i]);
 }
@@ -1458,7 +1493,7 @@ void tiled_reduce_kernel(int R, int first_tile, int num_tiles, const int2* __res
 // phase 2 with the PageRank update fused into the tile write-out (cf. pr_step_kernel)
 template <int kReduceBlock>
 __global__ __launch_bounds__(kReduceBlock, kReduceBlock / 128)
-void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__ cells_t, int num_strips,
+void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int* __restrict__ pass_first, const PassDesc* __restrict__ pass_desc,
                                   const float* __restrict__ prod,
                                   const unsigned char* __restrict__ a_drow,
                                   const LongSeeds seeds,
@@ -1471,7 +1506,7 @@ void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int2* __restrict__
     extern __shared__ double tile[];
     const int tile_index = xcd_contiguous(blockIdx.x, num_tiles);
     if (tile_index < 0) return;
-    tile_accumulate_stream<kReduceBlock, SPMV_STREAM_SEGS>(tile, R, tile_index, num_strips, local_rows, cells_t, prod, a_drow, seeds);
+    tile_accumulate(tile, R, tile_index, pass_first, pass_desc, prod, a_drow, seeds);
 
     const float teleport = __fdiv_rn(1.0f - damping, static_cast<float>(n_global));
     const float dangling_term = __fdiv_rn(__fmul_rn(damping, state->dangling_sum),
@@ -1625,20 +1660,13 @@ LongSeeds long_seeds(const TiledPlan& plan, const Scratch& sc) {
     return LongSeeds{plan.long_rows, plan.long_first, plan.num_long > 0 ? plan.tile_long : nullptr, sc.long_sums};
 }
 
-constexpr int kReduceThreads = 1024;
-
-hipError_t launch_reduce(const TiledPlan& plan, const Scratch& sc, int first_tile, int num_tiles, float* d_y, hipStream_t s) {
+hipError_t launch_reduce(const TiledPlan& plan, const Scratch& sc, float* d_y, hipStream_t s) {
     const size_t lds = static_cast<size_t>(plan.tile_rows) * sizeof(double);
     const void* kernel = reinterpret_cast<const void*>(&tiled_reduce_kernel<kReduceThreads>);
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
-#if defined(SPMV_PROBE_P2) && SPMV_PROBE_P2 >= 16       // timing probe: phase 2 reads the VALUE array (same size, not freshly written) in place of the products
-    const float* probe_source = plan.a_val ? plan.a_val : sc.prod;
-#else
-    const float* probe_source = sc.prod;
-#endif
-    tiled_reduce_kernel<kReduceThreads><<<xcd_grid(num_tiles), kReduceThreads, lds, s>>>(
-        plan.tile_rows, first_tile, num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, probe_source, plan.a_drow,
+    tiled_reduce_kernel<kReduceThreads><<<xcd_grid(plan.num_tiles), kReduceThreads, lds, s>>>(
+        plan.tile_rows, plan.num_tiles, plan.pass_first, reinterpret_cast<const PassDesc*>(plan.pass_desc), sc.prod, plan.a_drow,
         long_seeds(plan, sc), plan.num_rows, d_y);
     return hipGetLastError();
 }
@@ -1652,7 +1680,7 @@ hipError_t launch_pagerank_reduce(const TiledPlan& plan, const Scratch& sc, cons
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
     tiled_pagerank_reduce_kernel<kReduceThreads><<<xcd_grid(plan.num_tiles), kReduceThreads, lds, s>>>(
-        plan.tile_rows, plan.num_tiles, reinterpret_cast<const int2*>(plan.cells_t), plan.num_strips, sc.prod, plan.a_drow,
+        plan.tile_rows, plan.num_tiles, plan.pass_first, reinterpret_cast<const PassDesc*>(plan.pass_desc), sc.prod, plan.a_drow,
         long_seeds(plan, sc), plan.num_rows, map, n_global, d_r_old, d_r_new, d_dangling, damping, d_state,
         d_block_partials, push);
     return hipGetLastError();
@@ -1728,14 +1756,12 @@ hipError_t tiled_build(const ELLMatrix* A, TiledPlan** out, hipStream_t s) {
 void tiled_free(TiledPlan* p) {
     if (!p) return;
     void* owned[] = {p->a_val, p->a_lcol, p->a_drow, p->prod, p->cells_t, p->items, p->long_rows, p->long_chunks,
-                     p->long_first, p->long_sums, p->tile_long, p->col_weight};
+                     p->long_first, p->long_sums, p->tile_long, p->col_weight, p->pass_first, p->pass_desc};
     for (void* q : owned) if (q) (void)hipFree(q);
     for (const TiledPlan::StreamScratch& e : p->extra_scratch) {
         if (e.prod) (void)hipFree(e.prod);
         if (e.long_sums) (void)hipFree(e.long_sums);
     }
-    for (hipEvent_t ev : p->part_events) if (ev) (void)hipEventDestroy(ev);
-    if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
     delete[] p->strip_first_item;
     delete p;
 }
@@ -1998,6 +2024,30 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         return fail(err);
     };
     if (e != hipSuccess) return fail_with_strip(e);
+    {   // phase 2's passes (pass_layout_kernel): counted, scanned, then written — a pure function of the cell table and the deltas
+        const int waves = plan->num_tiles * kReduceWaves;
+        e = dev_alloc(&plan->pass_first, static_cast<long long>(waves) + 1);
+        if (e != hipSuccess) return fail_with_strip(e);
+        const int2* cells = reinterpret_cast<const int2*>(plan->cells_t);
+        pass_layout_kernel<false><<<plan->num_tiles, kReduceThreads, 0, s>>>(plan->num_tiles, plan->num_strips, cells, plan->a_drow,
+                                                                            plan->pass_first, nullptr, nullptr);
+        exclusive_scan_small_kernel<<<1, kScanBlock, 0, s>>>(plan->pass_first, waves);
+        int total = 0;
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, plan->pass_first + waves, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) {
+            plan->num_passes = total;
+            e = hipMalloc(&plan->pass_desc, static_cast<size_t>(std::max(total, 1)) * sizeof(PassDesc));
+        }
+        if (e != hipSuccess) return fail_with_strip(e);
+        pass_layout_kernel<true><<<plan->num_tiles, kReduceThreads, 0, s>>>(plan->num_tiles, plan->num_strips, cells, plan->a_drow, nullptr,
+                                                                           plan->pass_first, static_cast<PassDesc*>(plan->pass_desc));
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail_with_strip(e);
+        trace.mark("phase-2 pass layout");
+    }
+
     if (A && plan->num_long > 0) {
         // cut the long rows into wavefront-sized chunks (the list is short: <= nnz / long_row rows)
         std::vector<int> rows(plan->num_long);
@@ -2134,43 +2184,6 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     }
     plan->num_items = static_cast<int>(items.size() / 3);
     plan->strip_first_item[plan->num_strips] = plan->num_items;
-    plan->num_parts = static_cast<int>(std::max(1LL, std::min({debug_number("parts", 1), 32LL, static_cast<long long>(plan->num_tiles)})));
-    if (plan->num_parts > 1) {
-        const int n = plan->num_parts, S = plan->num_strips;
-        std::vector<std::vector<int>> bound(n + 1, std::vector<int>(S));
-        std::vector<int> row(2 * static_cast<size_t>(S));
-        plan->part_first_tile.assign(n + 1, 0);
-        for (int p = 0; p <= n; ++p) plan->part_first_tile[p] = static_cast<int>(static_cast<long long>(plan->num_tiles) * p / n);
-        for (int strip = 0; strip < S; ++strip) {
-            bound[0][strip] = host_strip[strip];
-            bound[n][strip] = host_strip[strip + 1];
-        }
-        for (int p = 1; p < n; ++p) {
-            e = hipMemcpy(row.data(), plan->cells_t + 2LL * plan->part_first_tile[p] * S, row.size() * sizeof(int), hipMemcpyDeviceToHost);
-            if (e != hipSuccess) return fail(e);
-            for (int strip = 0; strip < S; ++strip) bound[p][strip] = row[2 * strip];
-        }
-        plan->part_first_item.assign(n + 1, 0);
-        for (int p = 0; p < n; ++p) {
-            plan->part_first_item[p] = static_cast<int>(items.size() / 3);
-            for (int strip = 0; strip < S; ++strip) {
-                const int begin = bound[p][strip], stop = bound[p + 1][strip];
-                const int pieces = (stop - begin + item_entries - 1) / item_entries;
-                int b = begin;
-                for (int piece = 1; piece <= pieces; ++piece) {
-                    int next = piece == pieces ? stop
-                                               : static_cast<int>(begin + static_cast<long long>(stop - begin) * piece / pieces) / 8 * 8;
-                    next = std::max(next, b);
-                    if (next == b && piece != pieces) continue;
-                    items.push_back(strip);
-                    items.push_back(b);
-                    items.push_back(next);
-                    b = next;
-                }
-            }
-        }
-        plan->part_first_item[n] = static_cast<int>(items.size() / 3);
-    }
     e = dev_alloc(&plan->items, static_cast<long long>(items.size()));
     if (e == hipSuccess && !items.empty()) {
         e = hipMemcpy(plan->items, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice);
@@ -2179,6 +2192,7 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
 
     trace.mark("fold probe, long rows, items");
     plan->plan_bytes = plan->nnz * (4 /*prod*/ + 2 + 1 + (plan->a_val ? 4 : 0)) + cells * 8 +
+                       plan->num_passes * static_cast<long long>(sizeof(PassDesc)) + 4LL * (plan->num_tiles * kReduceWaves + 1) +
                        (plan->col_weight ? 4LL * plan->num_cols : 0) +
                        12LL * plan->num_items + 12LL * plan->num_long_chunks;
     plan->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -2244,43 +2258,9 @@ hipError_t tiled_spmv(const TiledPlan& plan, const float* d_x, float* d_y, hipSt
     if (e != hipSuccess) return e;
     // two host threads may call on the same stream: the pair of launches must not interleave with another pair
     std::lock_guard<std::mutex> pair(plan.launch_lock);
-    if (plan.num_parts > 1) {
-        // EXPERIMENT: phase 2 of part p on a side stream beside phase 1 of part p + 1
-        const int n = plan.num_parts;
-        if (!plan.side_stream) {
-            if ((e = hipStreamCreateWithFlags(&plan.side_stream, hipStreamNonBlocking)) != hipSuccess) return e;
-            plan.part_events.assign(n, nullptr);
-            for (int p = 0; p < n; ++p) {
-                if ((e = hipEventCreateWithFlags(&plan.part_events[p], hipEventDisableTiming)) != hipSuccess) return e;
-            }
-        }
-        const std::vector<int>& fi = plan.part_first_item;
-        const std::vector<int>& ft = plan.part_first_tile;
-        if (debug_option("parts_seq")) {
-            // EXPERIMENT: part by part on ONE stream — phase 2 of a part reads its products right behind phase 1
-            // (while they are still in the Infinity Cache)
-            for (int p = 0; p < n; ++p) {
-                e = launch_expand(plan, sc, fi[p], fi[p + 1] - fi[p], p == 0, d_x, nullptr, s);
-                if (e == hipSuccess) e = launch_reduce(plan, sc, ft[p], ft[p + 1] - ft[p], d_y, s);
-                if (e != hipSuccess) return e;
-            }
-            return hipSuccess;
-        }
-        e = launch_expand(plan, sc, fi[0], fi[1] - fi[0], true, d_x, nullptr, s);
-        for (int p = 1; p < n && e == hipSuccess; ++p) {
-            e = hipEventRecord(plan.part_events[p - 1], s);
-            if (e == hipSuccess) e = hipStreamWaitEvent(plan.side_stream, plan.part_events[p - 1], 0);
-            if (e == hipSuccess) e = launch_reduce(plan, sc, ft[p - 1], ft[p] - ft[p - 1], d_y, plan.side_stream);
-            if (e == hipSuccess) e = launch_expand(plan, sc, fi[p], fi[p + 1] - fi[p], false, d_x, nullptr, s);
-        }
-        if (e == hipSuccess) e = launch_reduce(plan, sc, ft[n - 1], ft[n] - ft[n - 1], d_y, s);
-        if (e == hipSuccess) e = hipEventRecord(plan.part_events[n - 1], plan.side_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s, plan.part_events[n - 1], 0);
-        return e;
-    }
     e = launch_expand(plan, sc, 0, plan.num_items, true, d_x, nullptr, s);       // phase 1 + the long rows
     if (e != hipSuccess) return e;
-    return launch_reduce(plan, sc, 0, plan.num_tiles, d_y, s);
+    return launch_reduce(plan, sc, d_y, s);
 }
 
 // After convergence the kernels of both parts return at once: r_new and the product stream stay as the last

@@ -375,9 +375,16 @@ def main():
             pmc = json.load(open(pmc_file))
             same_shape = all(pmc.get("plan", {}).get(k) == plan_info.get(k)
                              for k in ("strip_cols", "tile_rows", "num_strips", "num_tiles", "slots_in_cells"))
-            if same_shape:
+            import hashlib
+            same_sources = all(
+                hashlib.sha256(open(os.path.join(ROOT, "gpu-spmv_amd", "csrc", name), "rb").read()).hexdigest() == digest
+                for name, digest in pmc.get("sources_sha256", {"missing": ""}).items()) if pmc.get("sources_sha256") else False
+            if same_shape and same_sources:
                 traffic = pmc.get("pr_step_kernel_bytes_per_launch")
-                traffic_source = "profiles/pmc_traffic.json (%s)" % pmc.get("collected", "separate rocprofv3 --pmc passes")
+                traffic_source = "profiles/pmc_traffic.json (commit %s; %s)" % (pmc.get("commit", "?"), pmc.get("collected", "separate rocprofv3 --pmc passes"))
+            elif same_shape:
+                traffic_source = ("profiles/pmc_traffic.json was collected on other kernel sources (commit %s): not reported"
+                                  % pmc.get("commit", "?"))
             else:
                 traffic_source = "profiles/pmc_traffic.json describes another plan shape: not reported"
         except Exception:
@@ -395,8 +402,11 @@ def main():
                 "traffic_frac": traffic_frac,
                 "floor_note": ("frac = algorithmic bytes / kernel time / peak; traffic_frac = the bytes the kernels really moved "
                                "(PMC) over the same time: the two-phase engine streams 15 B per entry (7 B of bucketed matrix + "
-                               "a 4 B product written and read back) against the byte model's 8 B, at the rate the L2-miss path "
-                               "sustains for that read/write mix (profiles/r02_mall_bench.txt, r03_fused_bench.txt)")
+                               "a 4 B product written and read back) against the byte model's 8 B; both kernels run within ~10 % of "
+                               "what plain streams of their bytes take on the same box (profiles/r04_phase2_bound.txt: phase 1 "
+                               "307-312 us against 297, phase 2 157 against ~140-156), and running the phases side by side or part "
+                               "by part through the Infinity Cache does not pay (profiles/r04_parts_overlap_rejected.txt, "
+                               "r04_infinity_cache_parts_rejected.txt)")
                               if tiled else None,
                 "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": local_bytes,
                 "tiled_plan": plan_info}

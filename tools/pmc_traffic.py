@@ -42,6 +42,11 @@ def main():
         if line.startswith("{"):
             plan = json.loads(line)["roofline"]["tiled_plan"]
             out["plan"] = {k: plan[k] for k in ("strip_cols", "tile_rows", "num_strips", "num_tiles", "slots_in_cells")}
+    # which build the passes ran on: bench.py reports the traffic only while the kernels' sources are the ones measured
+    import hashlib
+    out["sources_sha256"] = {name: hashlib.sha256(open(os.path.join(ROOT, "gpu-spmv_amd", "csrc", name), "rb").read()).hexdigest()
+                             for name in ("tiled.hip", "pagerank.hip")}
+    out["commit"] = os.environ.get("SPMV_COMMIT", "unknown (set SPMV_COMMIT=$(git rev-parse --short HEAD) in the gpurun command)")
     import datetime
     out["collected"] = "tools/pmc_traffic.sh, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s" % (
         datetime.date.today().isoformat())

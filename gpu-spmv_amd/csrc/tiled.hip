@@ -1171,17 +1171,23 @@ void tiled_expand_kernel(const int* __restrict__ items, int first_item, int num_
     __syncthreads();
 
     if (FOLD) {
-        // eight entries per lane per step: one 16-byte index load, two 16-byte product stores
-        for (int q = (begin & ~7) + threadIdx.x * 8; q < end; q += kExpandBlock * 8) {
-            if (q >= begin && q + 7 < end) {
-                const u16x8 c = *reinterpret_cast<const u16x8*>(a_lcol + q);
-                f32x4 lo, hi;
-                lo[0] = xs[c[0]]; lo[1] = xs[c[1]]; lo[2] = xs[c[2]]; lo[3] = xs[c[3]];
-                hi[0] = xs[c[4]]; hi[1] = xs[c[5]]; hi[2] = xs[c[6]]; hi[3] = xs[c[7]];
-                store_product(reinterpret_cast<f32x4*>(prod + q), lo);
-                store_product(reinterpret_cast<f32x4*>(prod + q + 4), hi);
-            } else {
-                for (int k = max(q, begin); k < min(q + 8, end); ++k) prod[k] = xs[a_lcol[k]];
+        // four entries per lane per group, two groups a workgroup-stride apart per step: every store instruction writes
+        // one contiguous KB per wavefront (round 3's eight consecutive entries per lane made each instruction write every
+        // other 16 bytes; harmless with plain stores, which meet in L2, but 31 % more write traffic with the non-temporal
+        // ones: WRITE_SIZE 826 against 631 MB on C5)
+        constexpr int kStride = kExpandBlock * 4;
+        for (int q = (begin & ~3) + threadIdx.x * 4; q < end; q += 2 * kStride) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int g = q + u * kStride;
+                if (g >= begin && g + 3 < end) {
+                    const u16x4 c = *reinterpret_cast<const u16x4*>(a_lcol + g);
+                    f32x4 p;
+                    p[0] = xs[c[0]]; p[1] = xs[c[1]]; p[2] = xs[c[2]]; p[3] = xs[c[3]];
+                    store_product(reinterpret_cast<f32x4*>(prod + g), p);
+                } else {
+                    for (int k = max(g, begin); k < min(g + 4, end); ++k) prod[k] = xs[a_lcol[k]];
+                }
             }
         }
         return;

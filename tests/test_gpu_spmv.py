@@ -742,11 +742,12 @@ def _csr_from_lengths_and_cols(lens, col_fn, rng):
     return rp.astype(np.int32), ci, va
 
 
-@pytest.mark.parametrize("shape", ["banded", "one_strip", "few_long_rows", "duplicate_columns", "dense_column",
+@pytest.mark.parametrize("shape", ["banded", "banded_dense", "one_strip", "few_long_rows", "duplicate_columns", "dense_column",
                                    "unsorted_columns", "explicit_zeros"])
 def test_tiled_engine_adversarial_structure(gpu, oracle, shape):
     """Structures that stress the cells of the tiled engine: every entry of a row in one strip
-    (banded), every entry of the matrix in one strip, rows far longer than the long-row limit,
+    (banded; banded_dense: 48 per row, so that ONE wavefront's run holds far more than the 64 passes whose descriptors it
+    fetches at a time), every entry of the matrix in one strip, rows far longer than the long-row limit,
     repeated (row, column) pairs, one column referenced by every row, rows whose columns are stored in descending
     order (legal CSR; the reference never sorts), stored zeros (values and a whole column of them)."""
     rng = np.random.default_rng(17)
@@ -754,6 +755,10 @@ def test_tiled_engine_adversarial_structure(gpu, oracle, shape):
         rows = cols = 300_000
         lens = np.full(rows, 16)
         rp, ci, va = _csr_from_lengths_and_cols(lens, lambda r, s: np.clip(r - 8 + s, 0, cols - 1), rng)
+    elif shape == "banded_dense":
+        rows = cols = 200_000
+        lens = np.full(rows, 48)
+        rp, ci, va = _csr_from_lengths_and_cols(lens, lambda r, s: np.clip(r - 24 + s, 0, cols - 1), rng)
     elif shape == "one_strip":
         rows, cols = 400_000, 200_000
         lens = np.full(rows, 8)

@@ -21,10 +21,11 @@
 //   phase 2 "reduce" : a workgroup (1024 threads) owns one row tile: R rows of DOUBLES in dynamic LDS, R a
 //        multiple of 64 up to 9984 = 78 KiB, two tiles per CU, R stretched so that the tiles fill whole rounds
 //        of the 512 resident workgroups.  The tile's slots are one contiguous run per strip (cell table); a
-//        wavefront takes a run, loads 4 products (16 B) + 4 row deltas (4 B) per lane, rebuilds the rows with an
-//        in-lane prefix and one DPP wavefront scan, adds each product into the tile with the hardware
-//        ds_add_f64 and finally the tile is rounded to fp32 and written out with coalesced stores (optionally
-//        through the fused PageRank update).  Why doubles: gfx950's ds_add_f32 runs at 0.38 lanes/clk/CU, a
+//        wavefront walks the runs of its share of the strips as one stream of 256-slot PASSES whose geometry was
+//        laid out when the plan was built (pass descriptors, below): it loads 4 products (16 B) + 4 row deltas
+//        (4 B) per lane, rebuilds the rows with an in-lane prefix and one DPP wavefront scan, adds each product
+//        into the tile with the hardware ds_add_f64 and finally the tile is rounded to fp32 and written out with
+//        coalesced stores (optionally through the fused PageRank update).  Why doubles: gfx950's ds_add_f32 runs at 0.38 lanes/clk/CU, a
 //        compare-and-swap add at 3.4 but with retry storms when the tile's wavefronts meet on hot rows (round
 //        1: phase 2 VALU-bound at ~225 us whatever was changed), ds_add_f64 at 3.5 (8.6 on consecutive rows)
 //        with no retries (tools/lds_bench.hip, profiles/r02_lds_bench.txt, r02_phase2_counters.txt).

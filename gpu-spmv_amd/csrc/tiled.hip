@@ -1930,10 +1930,17 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     if (e == hipSuccess) e = dev_alloc(&plan->a_lcol, plan->nnz + 8);
     if (e == hipSuccess) e = dev_alloc(&plan->a_drow, plan->nnz + 8);
     if (e == hipSuccess) e = dev_alloc(&plan->cells_t, 2 * cells);
+    const int pass_waves = T * kReduceWaves;
+    if (e == hipSuccess) e = dev_alloc(&plan->pass_first, static_cast<long long>(pass_waves) + 1);
     if (e != hipSuccess) return cleanup(e);
     {   // the tile-major cell table first: the placing kernels read their tile's cell begins from it (one contiguous read)
         const int grid = static_cast<int>(std::min<long long>((cells + kBlock) / kBlock, 4096));
         cell_table_kernel<<<grid, kBlock, 0, s>>>(offs, S, T, reinterpret_cast<int2*>(plan->cells_t), strip_begin);
+        // phase 2's passes are a function of the cell table alone: counted and scanned here, beside the placing pass, so that
+        // their total arrives with this function's last synchronisation (the descriptors are written by build_plan)
+        pass_layout_kernel<false><<<T, kReduceThreads, 0, s>>>(T, S, reinterpret_cast<const int2*>(plan->cells_t), nullptr, plan->pass_first,
+                                                              nullptr, nullptr);
+        exclusive_scan_small_kernel<<<1, kScanBlock, 0, s>>>(plan->pass_first, pass_waves);
     }
     if (plan->nnz > 0) {
         // staged placing pass (contiguous segments); the batches it cannot hold are flagged for the scattered one
@@ -1966,8 +1973,11 @@ hipError_t build_cells(const Src& dev_src, bool has_long_path, TiledPlan* plan, 
     host_strip->assign(S + 1, 0);
     if (e == hipSuccess) e = hipMemcpyAsync(host_strip->data(), strip_begin, host_strip->size() * sizeof(int),
                                             hipMemcpyDeviceToHost, s);
+    int pass_total = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&pass_total, plan->pass_first + pass_waves, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return cleanup(e);
+    plan->num_passes = pass_total;
     trace.mark("allocations + placing (sync)");
     // strip_begin is needed again by the fold probe: hand it to the plan's scratch (freed by the caller)
     plan->items = strip_begin;          // temporarily; build_plan replaces it
@@ -2031,28 +2041,15 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
         return fail(err);
     };
     if (e != hipSuccess) return fail_with_strip(e);
-    {   // phase 2's passes (pass_layout_kernel): counted, scanned, then written — a pure function of the cell table and the deltas
-        const int waves = plan->num_tiles * kReduceWaves;
-        e = dev_alloc(&plan->pass_first, static_cast<long long>(waves) + 1);
+    {   // phase 2's pass descriptors (pass_layout_kernel; counted and scanned beside the placing pass in build_cells)
+        e = hipMalloc(&plan->pass_desc, static_cast<size_t>(std::max<long long>(plan->num_passes, 1)) * sizeof(PassDesc));
         if (e != hipSuccess) return fail_with_strip(e);
-        const int2* cells = reinterpret_cast<const int2*>(plan->cells_t);
-        pass_layout_kernel<false><<<plan->num_tiles, kReduceThreads, 0, s>>>(plan->num_tiles, plan->num_strips, cells, plan->a_drow,
-                                                                            plan->pass_first, nullptr, nullptr);
-        exclusive_scan_small_kernel<<<1, kScanBlock, 0, s>>>(plan->pass_first, waves);
-        int total = 0;
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(&total, plan->pass_first + waves, sizeof(int), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e == hipSuccess) {
-            plan->num_passes = total;
-            e = hipMalloc(&plan->pass_desc, static_cast<size_t>(std::max(total, 1)) * sizeof(PassDesc));
-        }
-        if (e != hipSuccess) return fail_with_strip(e);
-        pass_layout_kernel<true><<<plan->num_tiles, kReduceThreads, 0, s>>>(plan->num_tiles, plan->num_strips, cells, plan->a_drow, nullptr,
+        pass_layout_kernel<true><<<plan->num_tiles, kReduceThreads, 0, s>>>(plan->num_tiles, plan->num_strips,
+                                                                           reinterpret_cast<const int2*>(plan->cells_t), plan->a_drow, nullptr,
                                                                            plan->pass_first, static_cast<PassDesc*>(plan->pass_desc));
         e = hipGetLastError();
         if (e != hipSuccess) return fail_with_strip(e);
-        trace.mark("phase-2 pass layout");
+        trace.mark("phase-2 pass descriptors");
     }
 
     if (A && plan->num_long > 0) {

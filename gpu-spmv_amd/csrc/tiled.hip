@@ -1141,10 +1141,38 @@ void tiled_expand_kernel(const int* __restrict__ items, int first_item, int num_
     const long long base = static_cast<long long>(strip) * W;
     const int width = static_cast<int>(min(static_cast<long long>(W), num_cols - base));
     const float* src = x + base;
+    // Staging the strip: whole rounds of the workgroup first, several 16-byte loads per lane in flight.  One load per iteration
+    // behind its own wait made a W = 16384 strip eight L2 latencies per item, ~20 % of a workgroup's life during which it
+    // streams nothing: C5 phase 1 322-328 -> 310-312 us with four in flight (two: 313-317; eight, or the entry loop below
+    // software-pipelined on top: no further change — profiles/r04_kernel_ab_descriptors.txt).
+    constexpr int kRound = kExpandBlock * 4;
+    constexpr int kInFlight = W / kRound >= 4 ? 4 : (W / kRound >= 2 ? 2 : 1);
     if (FOLD) {
         const float* wsrc = col_weight + base;            // hipMalloc'd and base % 4 == 0: always aligned
         const bool aligned = (reinterpret_cast<unsigned long long>(src) & 15) == 0;
-        for (int i = threadIdx.x * 4; i < width; i += kExpandBlock * 4) {
+        int i_block = 0;                                   // wave-uniform
+        if (aligned) {
+#pragma unroll 1
+            for (; i_block + kInFlight * kRound <= width; i_block += kInFlight * kRound) {
+                const int i = i_block + threadIdx.x * 4;
+                f32x4 xv[kInFlight], wv[kInFlight];
+#pragma unroll
+                for (int u = 0; u < kInFlight; ++u) {
+                    xv[u] = *reinterpret_cast<const f32x4*>(src + i + u * kRound);
+                    wv[u] = *reinterpret_cast<const f32x4*>(wsrc + i + u * kRound);
+                }
+#pragma unroll
+                for (int u = 0; u < kInFlight; ++u) {
+                    f32x4 z;
+                    z[0] = __fmul_rn(wv[u][0], xv[u][0]);
+                    z[1] = __fmul_rn(wv[u][1], xv[u][1]);
+                    z[2] = __fmul_rn(wv[u][2], xv[u][2]);
+                    z[3] = __fmul_rn(wv[u][3], xv[u][3]);
+                    *reinterpret_cast<f32x4*>(xs + i + u * kRound) = z;
+                }
+            }
+        }
+        for (int i = i_block + threadIdx.x * 4; i < width; i += kRound) {
             if (aligned && i + 3 < width) {
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(src + i);
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(wsrc + i);
@@ -1159,7 +1187,17 @@ void tiled_expand_kernel(const int* __restrict__ items, int first_item, int num_
             }
         }
     } else if ((reinterpret_cast<unsigned long long>(src) & 15) == 0) {
-        for (int i = threadIdx.x * 4; i < width; i += kExpandBlock * 4) {
+        int i_block = 0;                                   // wave-uniform
+#pragma unroll 1
+        for (; i_block + kInFlight * kRound <= width; i_block += kInFlight * kRound) {
+            const int i = i_block + threadIdx.x * 4;
+            f32x4 t[kInFlight];
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + i + u * kRound);
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) *reinterpret_cast<f32x4*>(xs + i + u * kRound) = t[u];
+        }
+        for (int i = i_block + threadIdx.x * 4; i < width; i += kRound) {
             if (i + 3 < width) {
                 *reinterpret_cast<f32x4*>(xs + i) = *reinterpret_cast<const f32x4*>(src + i);
             } else {
@@ -1193,9 +1231,10 @@ void tiled_expand_kernel(const int* __restrict__ items, int first_item, int num_
         }
         return;
     }
-    // four entries per lane per step, groups aligned to 4 entries (16-byte loads and stores).  (Round 4 tried four groups
-    // per lane with all loads issued up front, and the same for the strip staging above: 311.8 against 306.9 us on C5,
-    // profiles/r04_kernel_ab_descriptors.txt — phase 1 runs at the rate its 10 bytes per slot allow, not at a latency bound.)
+    // four entries per lane per step, groups aligned to 4 entries (16-byte loads and stores).  (Round 4 tried 2 / 4 / 8 groups
+    // per lane with all loads issued up front, and the next group's loads in flight while this one is multiplied: no gain,
+    // the bunched forms lose 1-2 % — profiles/r04_kernel_ab_descriptors.txt; once a workgroup streams, phase 1 runs at the
+    // rate its 10 bytes per slot allow.  What paid was the start of a workgroup's life: the staging above.)
     for (int q = (begin & ~3) + threadIdx.x * 4; q < end; q += kExpandBlock * 4) {
         if (q >= begin && q + 3 < end) {
             const u16x4 c = *reinterpret_cast<const u16x4*>(a_lcol + q);

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 out=gpurun_out/kernel_ab.txt
 mkdir -p gpurun_out; : > $out
 WHICH=${WHICH:-c5only}
-for round in 1 2; do
+for round in $(seq 1 ${ROUNDS:-2}); do
   i=0
   for spec in "$@"; do
     i=$((i + 1))

@@ -841,7 +841,9 @@ def cpu_pagerank_baseline(row_ptrs, cols, vals, n, iterations, gpu_call):
            "final_residual": residual, "rank_sum": float(ranks.sum(dtype=np.float64)),
            "sample": "oracle_pagerank (the host loop of src/pagerank.cu:50-153 restated in C; src/pagerank.cu itself needs the CUDA "
                      "runtime to link) on the full workload matrix, %d iterations (what the GPU pagerank() call took), tolerance 0; "
-                     "value = iterations / (total - dangling scan)" % done}
+                     "value = iterations / (total - dangling scan); rank_sum is what the reference's arithmetic gives at this size "
+                     "(src/pagerank.cu:140-150 normalises by an fp32 running sum over n values: at n = 1e7 it stops growing near "
+                     "0.93 — SURVEY.md H5; the GPU path sums in double)" % done}
     if gpu_call and gpu_call.get("iterations"):
         out["gpu_iterations_per_s_incl_setup"] = round(gpu_call["iterations"] / max(gpu_call["seconds_total"], 1e-9), 1)
     return out

@@ -169,3 +169,22 @@ def test_tool_libraries_that_initialise_the_gpu_keep_the_run_in_process(monkeypa
     assert not bench._under_profiler()
     monkeypatch.setenv(name, value)
     assert bench._under_profiler()
+
+
+def test_cpu_pagerank_baseline_runs_the_reference_host_loop_for_the_asked_iterations():
+    """bench.py's `cpu_baseline.pagerank`: the oracle's restatement of the reference's host loop,
+    tolerance 0, exactly as many iterations as the GPU call took; iterations/s excludes the one-time dangling scan."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    n, k = 2000, 6
+    rng = np.random.default_rng(3)
+    cols = np.sort(rng.integers(0, n, size=(n, k)), axis=1).astype(np.int32).ravel()
+    counts = np.bincount(cols, minlength=n).astype(np.float32)
+    vals = (1.0 / counts[cols]).astype(np.float32)
+    row_ptrs = (np.arange(n + 1) * k).astype(np.int32)
+    out = bench.cpu_pagerank_baseline(torch.from_numpy(row_ptrs), torch.from_numpy(cols), torch.from_numpy(vals), n, 3,
+                                      {"iterations": 3, "seconds_total": 0.0025})
+    assert out["iterations"] == 3 and out["cores"] == 1 and out["unit"] == "iterations/s" and out["value"] > 0
+    assert out["kind"] == "port" and abs(out["rank_sum"] - 1.0) < 1e-3 and out["gpu_iterations_per_s_incl_setup"] == 1200.0

@@ -1559,14 +1559,44 @@ void tiled_pagerank_reduce_kernel(int R, int num_tiles, const int* __restrict__ 
                                           static_cast<float>(n_global));
     double res2 = 0.0, mass = 0.0;
     const long long first = static_cast<long long>(tile_index) * R;
-    for (int i = threadIdx.x; i < R && first + i < local_rows; i += kReduceBlock) {
-        const long long node = map.at(first + i);
-        const float fresh = __fadd_rn(__fadd_rn(__fmul_rn(damping, static_cast<float>(tile[i])), dangling_term), teleport);
-        r_new[node] = fresh;
-        for (int p = 0; p < push.count; ++p) push.ptr[p][node] = fresh;     // straight into the peers' vectors
-        const float diff = __fsub_rn(fresh, r_old[node]);
-        res2 += static_cast<double>(__fmul_rn(diff, diff));
-        if (dangling[node]) mass += static_cast<double>(fresh);
+    if (map.piece == 0x7fffffff && push.count == 0) {
+        // The usual case (one contiguous slice, no peer stores).  The update needs r_old and the dangling flag of the tile's
+        // rows: read inside the loop they were one full memory latency per row and thread, ten in a row (the loop below waits
+        // vmcnt(0) in every iteration: +22 us per step on C5, 182 against 160 us for the plain reduce); here all of a
+        // thread's loads go out together, in front of the arithmetic.  Same operations in the same order: same bits.
+        constexpr int kPerThread = (kMaxTileRows + kReduceBlock - 1) / kReduceBlock;
+        const long long node_first = map.base + first;
+        const int rows_here = static_cast<int>(min(static_cast<long long>(R), local_rows - first));     // >= 1: the tile exists
+        float old_rank[kPerThread];
+        unsigned char is_dangling[kPerThread];
+        // (unconditional loads at clamped rows: a guarded load is a branch, and the compiler waits for each behind its join)
+#pragma unroll
+        for (int u = 0; u < kPerThread; ++u) {
+            const int i = min(static_cast<int>(threadIdx.x) + u * kReduceBlock, rows_here - 1);
+            old_rank[u] = r_old[node_first + i];
+            is_dangling[u] = dangling[node_first + i];
+        }
+#pragma unroll
+        for (int u = 0; u < kPerThread; ++u) {
+            const int i = threadIdx.x + u * kReduceBlock;
+            if (i < rows_here) {
+                const float fresh = __fadd_rn(__fadd_rn(__fmul_rn(damping, static_cast<float>(tile[i])), dangling_term), teleport);
+                r_new[node_first + i] = fresh;
+                const float diff = __fsub_rn(fresh, old_rank[u]);
+                res2 += static_cast<double>(__fmul_rn(diff, diff));
+                if (is_dangling[u]) mass += static_cast<double>(fresh);
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < R && first + i < local_rows; i += kReduceBlock) {
+            const long long node = map.at(first + i);
+            const float fresh = __fadd_rn(__fadd_rn(__fmul_rn(damping, static_cast<float>(tile[i])), dangling_term), teleport);
+            r_new[node] = fresh;
+            for (int p = 0; p < push.count; ++p) push.ptr[p][node] = fresh;     // straight into the peers' vectors
+            const float diff = __fsub_rn(fresh, r_old[node]);
+            res2 += static_cast<double>(__fmul_rn(diff, diff));
+            if (dangling[node]) mass += static_cast<double>(fresh);
+        }
     }
     block_sum2<kReduceBlock>(res2, mass);
     if (threadIdx.x == 0) {

@@ -73,7 +73,10 @@ using namespace dev;
 // (choose_shape below):
 //   W in {4096, 8192, 16384, 32768} = 16 .. 128 KiB of static LDS in phase 1 (template instantiations)
 //   R = any multiple of 64 in [64, kMaxTileRows]: dynamic LDS in phase 2
-constexpr int kMaxItemEntries = 65536;   // phase-1 work item size bounds (entries)
+constexpr int kMaxItemEntries = 16384;   // phase-1 work item size bounds (entries).  Round 4: 65536 -> 16384 — with the strip staging
+                                         // pipelined, many short workgroups balance better than few long ones (C5 phase 1: 321.7 us with
+                                         // ~53 K-slot items, 332.6 with 44 K (7.16 rounds of 512), 315.9 with 29 K, 315.2 with 22 K, 310.8-311.4 with
+                                         // 15.5 K; on a faster box 296-300 / 290-295 (16 K) / 292-294 (12 K) / 308-311 (8 K))
 constexpr int kMinItemEntries = 4096;
 constexpr int kMaxLongRow = 4096;     // rows longer than min(this, 8 entries per strip) bypass the cells
 constexpr int kLongChunk = 512;       // entries per wavefront of the long-row path
@@ -1112,39 +1115,16 @@ __device__ __forceinline__ void long_row_chunk(const LongRows& lr, int which, co
     if ((threadIdx.x & 63) == 0) lr.chunk_sum[which] = acc;
 }
 
-// FOLD: the plan holds one weight per column instead of a value per entry; the strip is staged
-// as w_j * x_j and an entry's product is a plain LDS read (the same rounded product as a_ij * x_j).
+// Stages x strip `strip` (W columns from `base`) into xs.  FOLD: as w_j * x_j (one rounded product per column).
+// Whole rounds of the workgroup first, several 16-byte loads per lane in flight.  One load per iteration behind its own wait
+// made a W = 16384 strip eight L2 latencies per item, ~20 % of a workgroup's life during which it streams nothing: C5
+// phase 1 322-328 -> 310-312 us with four in flight (two: 313-317; eight, or the entry loop software-pipelined on top:
+// no further change — profiles/r04_kernel_ab_descriptors.txt).
 template <int W, int kExpandBlock, bool FOLD>
-__global__ __launch_bounds__(kExpandBlock)
-void tiled_expand_kernel(const int* __restrict__ items, int first_item, int num_items, int long_blocks,
-                         const float* __restrict__ a_val,
-                         const unsigned short* __restrict__ a_lcol,
-                         const float* __restrict__ col_weight,
-                         const float* __restrict__ x, int num_cols,
-                         float* __restrict__ prod, LongRows long_rows,
-                         const PrState* __restrict__ state) {
-    // PageRank steps enqueued past convergence are no-ops
-    if (state && state->done) return;
-    if (static_cast<int>(blockIdx.x) < long_blocks) {     // the long-row workgroups go first (latency-bound)
-        constexpr int kPerBlock = kExpandBlock / 64;
-        long_row_chunk(long_rows, blockIdx.x * kPerBlock + (threadIdx.x >> 6), x);
-        return;
-    }
-    __shared__ float xs[W];
-    const int window = xcd_contiguous(blockIdx.x - long_blocks, num_items);   // long_blocks is a multiple of 8
-    if (window < 0) return;
-    const int item = first_item + window;
-    const int strip = items[3 * item];
-    const int begin = items[3 * item + 1];
-    const int end = items[3 * item + 2];
-
-    const long long base = static_cast<long long>(strip) * W;
+__device__ __forceinline__ void stage_strip(float* xs, const float* __restrict__ x, const float* __restrict__ col_weight,
+                                            long long base, int num_cols) {
     const int width = static_cast<int>(min(static_cast<long long>(W), num_cols - base));
     const float* src = x + base;
-    // Staging the strip: whole rounds of the workgroup first, several 16-byte loads per lane in flight.  One load per iteration
-    // behind its own wait made a W = 16384 strip eight L2 latencies per item, ~20 % of a workgroup's life during which it
-    // streams nothing: C5 phase 1 322-328 -> 310-312 us with four in flight (two: 313-317; eight, or the entry loop below
-    // software-pipelined on top: no further change — profiles/r04_kernel_ab_descriptors.txt).
     constexpr int kRound = kExpandBlock * 4;
     constexpr int kInFlight = W / kRound >= 4 ? 4 : (W / kRound >= 2 ? 2 : 1);
     if (FOLD) {
@@ -1207,14 +1187,18 @@ void tiled_expand_kernel(const int* __restrict__ items, int first_item, int num_
     } else {
         for (int i = threadIdx.x; i < width; i += kExpandBlock) xs[i] = src[i];
     }
-    __syncthreads();
+}
 
+// The products of the slots [begin, end) of the staged strip: value, local column -> value * xs[column], same order.
+template <int kExpandBlock, bool FOLD>
+__device__ __forceinline__ void expand_slots(const float* xs, int begin, int end, const float* __restrict__ a_val,
+                                             const unsigned short* __restrict__ a_lcol, float* __restrict__ prod) {
+    constexpr int kStride = kExpandBlock * 4;
     if (FOLD) {
         // four entries per lane per group, two groups a workgroup-stride apart per step: every store instruction writes
         // one contiguous KB per wavefront (round 3's eight consecutive entries per lane made each instruction write every
         // other 16 bytes; harmless with plain stores, which meet in L2, but 31 % more write traffic with the non-temporal
         // ones: WRITE_SIZE 826 against 631 MB on C5)
-        constexpr int kStride = kExpandBlock * 4;
         for (int q = (begin & ~3) + threadIdx.x * 4; q < end; q += 2 * kStride) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -1234,8 +1218,8 @@ void tiled_expand_kernel(const int* __restrict__ items, int first_item, int num_
     // four entries per lane per step, groups aligned to 4 entries (16-byte loads and stores).  (Round 4 tried 2 / 4 / 8 groups
     // per lane with all loads issued up front, and the next group's loads in flight while this one is multiplied: no gain,
     // the bunched forms lose 1-2 % — profiles/r04_kernel_ab_descriptors.txt; once a workgroup streams, phase 1 runs at the
-    // rate its 10 bytes per slot allow.  What paid was the start of a workgroup's life: the staging above.)
-    for (int q = (begin & ~3) + threadIdx.x * 4; q < end; q += kExpandBlock * 4) {
+    // rate its 10 bytes per slot allow.  What paid was the start of a workgroup's life: the staging.)
+    for (int q = (begin & ~3) + threadIdx.x * 4; q < end; q += kStride) {
         if (q >= begin && q + 3 < end) {
             const u16x4 c = *reinterpret_cast<const u16x4*>(a_lcol + q);
             const f32x4 v = *reinterpret_cast<const f32x4*>(a_val + q);
@@ -1249,6 +1233,38 @@ void tiled_expand_kernel(const int* __restrict__ items, int first_item, int num_
             for (int k = max(q, begin); k < min(q + 4, end); ++k) prod[k] = a_val[k] * xs[a_lcol[k]];
         }
     }
+}
+
+// FOLD: the plan holds one weight per column instead of a value per entry; the strip is staged
+// as w_j * x_j and an entry's product is a plain LDS read (the same rounded product as a_ij * x_j).
+// One workgroup per work item.  (Round 4 tried 2 / 3 / 5 CONSECUTIVE items per workgroup, staging a strip only when it changes:
+// 347 / 359 / 433 against 320 us on C5 — fewer, longer workgroups balance worse than their saved strip loads are worth.)
+template <int W, int kExpandBlock, bool FOLD>
+__global__ __launch_bounds__(kExpandBlock)
+void tiled_expand_kernel(const int* __restrict__ items, int first_item, int num_items, int long_blocks,
+                         const float* __restrict__ a_val,
+                         const unsigned short* __restrict__ a_lcol,
+                         const float* __restrict__ col_weight,
+                         const float* __restrict__ x, int num_cols,
+                         float* __restrict__ prod, LongRows long_rows,
+                         const PrState* __restrict__ state) {
+    // PageRank steps enqueued past convergence are no-ops
+    if (state && state->done) return;
+    if (static_cast<int>(blockIdx.x) < long_blocks) {     // the long-row workgroups go first (latency-bound)
+        constexpr int kPerBlock = kExpandBlock / 64;
+        long_row_chunk(long_rows, blockIdx.x * kPerBlock + (threadIdx.x >> 6), x);
+        return;
+    }
+    __shared__ float xs[W];
+    const int window = xcd_contiguous(blockIdx.x - long_blocks, num_items);   // long_blocks is a multiple of 8
+    if (window < 0) return;
+    const int item = first_item + window;
+    const int strip = items[3 * item];
+    const int begin = items[3 * item + 1];
+    const int end = items[3 * item + 2];
+    stage_strip<W, kExpandBlock, FOLD>(xs, x, col_weight, static_cast<long long>(strip) * W, num_cols);
+    __syncthreads();
+    expand_slots<kExpandBlock, FOLD>(xs, begin, end, a_val, a_lcol, prod);
 }
 
 // ------------------------------------------------------------------------ phase 2 ----
@@ -2234,8 +2250,8 @@ hipError_t build_plan(const Source& src, TiledPlan** out, hipStream_t s) {
     // phase-1 work items: every strip's range cut into EQUAL pieces of <= item_entries (enough
     // pieces to fill the chip several times), piece boundaries on multiples of 8 slots
     const long long floor_entries = std::max<long long>(kMinItemEntries, plan->strip_cols);   // strip load <= 40 % of the stream
-    int item_entries = static_cast<int>(std::min<long long>(
-        kMaxItemEntries, std::max<long long>(floor_entries, (plan->nnz / 2048 + 7) / 8 * 8)));
+    int item_entries = static_cast<int>(std::max<long long>(
+        floor_entries, std::min<long long>(kMaxItemEntries, (plan->nnz / 2048 + 7) / 8 * 8)));
     item_entries = static_cast<int>(std::max(1024LL, debug_number("item", item_entries)));
     std::vector<int> items;
     plan->strip_first_item = new int[static_cast<size_t>(plan->num_strips) + 1];

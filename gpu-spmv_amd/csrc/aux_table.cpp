@@ -189,6 +189,7 @@ PlanRef tiled_plan_for(const CSRMatrix* A, hipStream_t s) {
     if (aux->tiled && !plan_matches(aux->tiled, A)) {
         aux->tiled.reset();           // header or arrays changed under the same row-pointer array
         aux->tiled_failed = false;
+        ++aux->plan_replacements;     // (two matrices taking turns over one row-pointer array: promotion gives up on them)
     }
     if (!aux->tiled && !aux->tiled_failed) {
         const TraceRange range("spmv:tiled_plan_build");

@@ -82,6 +82,9 @@ struct CsrAux {
     // spmv_csr() calls on this matrix that named a REORDERING kernel (VECTOR_CSR / MERGE_PATH) without use_texture:
     // from the call after tiled_promotion() of them on, the plan is built and they take the tiled engine too
     std::atomic<int> reorder_calls{0};
+    // plans thrown away because another matrix over the same row-pointer array (the side table's key) wanted one: past
+    // two, promotion stops building for this key — callers that alternate such matrices would rebuild on every call
+    int plan_replacements = 0;
 };
 
 // Ski-rental promotion: the reference's own callers spell the kernel and never set use_texture

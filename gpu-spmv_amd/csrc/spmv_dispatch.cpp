@@ -123,7 +123,8 @@ void prepare_csr(const CSRMatrix* A, const SpMVConfig* config, hipStream_t strea
     // in front of the timed region, like every other one-time preparation
     if (reorders && !config->use_texture && tiled_promotion() > 0 && tiled_eligible(A)) {
         CsrAux* aux = aux_lookup(A->d_row_ptrs, true);
-        if (aux->reorder_calls.fetch_add(1, std::memory_order_relaxed) >= tiled_promotion() && tiled_plan_for(A, stream)) return;
+        if (aux->reorder_calls.fetch_add(1, std::memory_order_relaxed) >= tiled_promotion() && aux->plan_replacements <= 2 &&
+            tiled_plan_for(A, stream)) return;
         if (tiled_plan_if_cached(A)) return;
     }
     if (config->kernel_type == SpMVConfig::MERGE_PATH) (void)prepare_csr_merge(A, aux_lookup(A->d_row_ptrs, true), stream);

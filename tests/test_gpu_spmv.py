@@ -843,6 +843,23 @@ def test_callers_that_spell_the_kernel_are_promoted_to_the_tiled_engine(gpu, ora
             assert gpu.spmv_csr(A.handle, xd, y, vector, n).error_code == 0
             assert not gpu.csr_has_tiled_plan(A.handle)
         assert gpu.spmv_csr(A.handle, xd, y, vector, n).error_code == 0 and gpu.csr_has_tiled_plan(A.handle)
+        # two matrices taking turns over ONE row-pointer array (the side table's key; every k-per-row graph has the same
+        # one): the plan is replaced a few times, then promotion gives up on the key instead of rebuilding on every call
+        B = wl.uniform_csr_device(8, n, n, k)
+        shared = gpu.csr_wrap_device(n, n, n * k, A.row_ptrs.get(), B.col_indices.get(), B.values.get())
+        rpB, ciB, vaB = B.to_host()
+        wantB = oracle.spmv_csr(rpB, ciB, vaB, x)
+        builds = 0
+        for turn in range(12):
+            handle, ref = (A.handle, (rp, ci, va, want)) if turn % 2 == 0 else (shared, (rpB, ciB, vaB, wantB))
+            before = gpu.csr_tiled_info(handle)
+            assert gpu.spmv_csr(handle, xd, y, vector, n).error_code == 0
+            assert reorder_err(ref[0], ref[1], ref[2], x, ref[3], y.copyToHost(n)) <= REORDER_TOL, turn
+            after = gpu.csr_tiled_info(handle)
+            builds += 1 if after and (not before or after["build_ms"] != before["build_ms"]) else 0
+        assert builds <= 4, builds
+        gpu.csr_destroy(shared)
+        B.close()
         # a small matrix (below the engine's thresholds) is never promoted
         S = wl.uniform_csr_device(7, 20_000, 20_000, 8)
         xs = wl.vector_device(7, 1, 20_000)

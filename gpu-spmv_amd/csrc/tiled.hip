@@ -1787,10 +1787,11 @@ bool eligible_dims(long long rows, long long cols, long long nnz) {
         const char* env = std::getenv("SPMV_TILED");
         return !(env && env[0] == '0');
     }();
-    // measured crossover (tools/quick_bench.py crossover, 1 M rows x 16): 65536 columns tie
-    // (69 vs 71 us), 131072 columns 60 vs 74 us, 262144 columns 57 vs 76 us
-    // (SPMV_DEBUG=min_cols=1,min_nnz=1: tests force small matrices through the engine)
-    const long long min_cols = debug_number("min_cols", 65536LL);
+    // Everything wider than what one CU's LDS holds of x (<= 32768 columns: the x-in-LDS vector kernel).  Rounds 1-3 drew the line
+    // at 65536 columns (a tie then: 69 vs 71 us on 1 M rows x 16); with round 4's engine it wins from the first column past the
+    // LDS kernel's reach — 34000 columns: 43.7 against 65.5 us (1 M x 16), 92 against 150 us (4 M x 8); tools/crossover_probe.py,
+    // profiles/r04_crossover.txt.  (SPMV_DEBUG=min_cols=1,min_nnz=1: tests force small matrices through the engine)
+    const long long min_cols = debug_number("min_cols", 32769LL);
     const long long min_nnz = debug_number("min_nnz", 1LL << 20);
     if (!enabled || rows <= 0 || nnz < min_nnz || cols < min_cols) return false;
     int w = 0, r = 0;

@@ -74,7 +74,7 @@ int spmv_ell_async(const ELLMatrix* A, const float* d_x, float* d_y,
 
 // Promotion of callers that spell a reordering kernel without use_texture (the reference's own callers do:
 // benchmarks/main.cu:52-56, src/pagerank.cu:89-90): after `calls` spmv_csr() calls with VECTOR_CSR / MERGE_PATH on a
-// matrix the LDS-tiled engine would take (>= 65536 columns, >= 1 M entries), the next call builds the matrix's plan in
+// matrix the LDS-tiled engine would take (> 32768 columns, >= 1 M entries), the next call builds the matrix's plan in
 // front of its timed region and all later ones run on the engine — ~5x faster on a 10 M-row matrix; results stay within
 // the 1e-5 bound on both sides of the switch but low-order bits may change there.  Default 4; 0 = never promote
 // (environment: SPMV_TILED_PROMOTE=0).  SCALAR_CSR and spmv_ell keep their CPU-order kernels regardless.

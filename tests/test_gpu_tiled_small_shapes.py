@@ -1,4 +1,4 @@
-"""The LDS-tiled engine normally takes only large matrices (>= 65536 columns, >= 1 M entries).  This test
+"""The LDS-tiled engine normally takes only large matrices (> 32768 columns, >= 1 M entries).  This test
 lowers the thresholds (environment, read once per process => a worker process) and pushes ~150 SMALL matrices
 of awkward shapes through it — single row / column, sizes straddling the strip and tile sizes, ragged and
 empty rows, rows far beyond the long-row limit, value-folded columns, ELL sources — against the CPU oracle."""
